@@ -1,0 +1,116 @@
+"""CPU tests: the NumPy oracle (oracle/oracle_np.py) against the golden vectors produced by the
+real reference (oracle/gen_golden.py).  This is what "pins" the oracle: channels must agree to
+1e-12 absolute (the oracle follows the reference's dtype flow), integer side products exactly."""
+import numpy as np
+import pytest
+
+from oracle import oracle_np as onp
+from tests._cases import (golden_names, load_golden, oracle_params, fov_args, assert_channel_close)
+
+
+def _run(name, style):
+    case, rays, ue_rot, ref = load_golden(name)
+    params = oracle_params(case, ue_rot)
+    bs_fov, ue_fov = fov_args(case)
+    res = onp.compute_channels(rays, params, bs_fov, ue_fov, style=style)
+    return case, rays, ref, res, params
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_oracle_matches_reference(name):
+    case, rays, ref, res, params = _run(name, "batched")
+    H = res["channel"]
+    if "channel" in ref:
+        assert H.dtype == ref["channel"].dtype == np.complex64
+        assert_channel_close(H, ref["channel"], tol_rel=1e-7, tol_abs=1e-12, what=name)
+        # near bit-level: the oracle reproduces the dtype flow, only summation order may differ
+        fin = np.isfinite(ref["channel"])
+        assert np.max(np.abs(np.where(fin, H - ref["channel"], 0))) <= 1e-10
+    else:
+        sub = case["subsample"]
+        Hs = H[:, :, sub["tx"], :][..., sub["k"]]
+        assert_channel_close(Hs, ref["channel_sub"], tol_rel=1e-7, what=name)
+    np.testing.assert_array_equal(res["los"], ref["los"])
+    np.testing.assert_array_equal(res["num_paths"], ref["num_paths"])
+    if "fov_mask" in ref:
+        np.testing.assert_array_equal(res["_fov_mask"], ref["fov_mask"])
+    else:
+        assert res["_fov_mask"] is None
+    np.testing.assert_array_equal(res["power_linear"], ref["power_linear"])
+    np.testing.assert_array_equal(res["_power_linear_ant_gain"], ref["power_linear_ant_gain"])
+    for k in ("aod_el_rot", "aod_az_rot", "aoa_el_rot", "aoa_az_rot"):
+        np.testing.assert_array_equal(res["_" + k], ref[k])
+    if case["freq_domain"]:
+        assert res["delay_exceeds_symbol"] == bool(ref["warned"])
+
+
+@pytest.mark.parametrize("name", ["g01_plumbing", "g03_rot_fov", "g06_dipole", "g08_num_paths_nan"])
+def test_reference_style_loop_equals_batched(name):
+    """The per-user broadcast+nansum loop (what bench.py times as the CPU baseline) and the
+    batched einsum are the same arithmetic."""
+    _, _, ref, res_b, _ = _run(name, "batched")
+    _, _, _, res_r, _ = _run(name, "reference")
+    assert_channel_close(res_r["channel"], ref["channel"], tol_rel=1e-7, what=name)
+    assert_channel_close(res_r["channel"], res_b["channel"], tol_rel=1e-7, what=name)
+
+
+def test_doppler_term_matches_v3():
+    """v4 has no Doppler implementation; the v3 generator's term is the oracle (SURVEY finding 4)."""
+    case, rays, ue_rot, ref = load_golden("g10_doppler_v3")
+    params = oracle_params(case, ue_rot)
+    params["enable_doppler"] = 1
+    dop = dict(vel=rays["doppler_vel"], acc=rays["doppler_acc"], carrier_freq=3.5e9)
+    res = onp.compute_channels(rays, params, doppler=dop)
+    assert float(ref["v3_v4_maxdiff"]) < 1e-10
+    assert_channel_close(res["channel"], ref["channel_doppler"], tol_rel=1e-6, what="doppler")
+    # and it is not a no-op
+    assert np.max(np.abs(ref["channel_doppler"] - ref["channel"])) > 1e-3 * np.max(np.abs(ref["channel"]))
+
+
+def test_dipole_known_answers():
+    """reference test idea: test/test_ant_patterns.py:72-78 (max at 90 deg, nulls at 0/180)."""
+    g = onp.pattern_gain("halfwave-dipole", np.array([np.pi / 2, 0.0, np.pi, np.pi / 4, np.nan]))
+    assert g[0] == pytest.approx(1.643)
+    assert g[1] == 0 and g[2] == 0 and g[4] == 0
+    rel = (g[3] / g[0]) ** 2          # tx*rx relative gain at 45 deg, v4 formula (/sin, not /sin^2)
+    assert 0.0 < rel < 1.0
+    assert onp.pattern_gain("isotropic", np.zeros(3)) == 1.0
+    with pytest.raises(NotImplementedError):
+        onp.pattern_gain("patch", np.zeros(3))
+
+
+def test_ant_indices_order():
+    idx = onp.ant_indices([4, 2])
+    assert idx[:, 0].tolist() == [0] * 8
+    assert idx[:, 1].tolist() == [0, 1, 2, 3, 0, 1, 2, 3]
+    assert idx[:, 2].tolist() == [0, 0, 0, 0, 1, 1, 1, 1]
+
+
+def test_array_response_nan_column_and_batch_vs_scalar():
+    """reference test idea: test/test_array_response.py (batch == per-user, NaN edge cases)."""
+    rng = np.random.default_rng(5)
+    th = rng.uniform(0, np.pi, (6, 7))
+    ph = rng.uniform(-np.pi, np.pi, (6, 7))
+    th[2, 3:] = np.nan
+    ph[2, 3:] = np.nan
+    a = onp.array_response_batch([4, 2], 0.5, th, ph)
+    assert a.shape == (6, 8, 7)
+    assert np.all(a[2, :, 3:] == 0)
+    idx = onp.ant_indices([4, 2])
+    for i in (0, 2):
+        for l in range(3):
+            want = np.exp(1j * np.pi * (idx[:, 1] * np.sin(th[i, l]) * np.sin(ph[i, l]) + idx[:, 2] * np.cos(th[i, l])))
+            np.testing.assert_allclose(a[i, :, l], want, rtol=1e-12, atol=1e-12)
+
+
+def test_empty_and_all_nan_inputs():
+    rays = onp.synth_rays(0, 5, seed=1)
+    res = onp.compute_channels(rays, onp.make_params())
+    assert res["channel"].shape == (0, 1, 8, 1)
+    rays = onp.synth_rays(3, 4, seed=2)
+    for k in onp.RAY_KEYS:
+        rays[k][:] = np.nan
+    res = onp.compute_channels(rays, onp.make_params())
+    assert np.all(res["channel"] == 0)
+    assert res["los"].tolist() == [-1, -1, -1]
+    assert res["num_paths"].tolist() == [0, 0, 0]
