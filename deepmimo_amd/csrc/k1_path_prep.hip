@@ -1,0 +1,282 @@
+// Stage 1 - path prep: one wavefront (64 lanes) per user, one lane per path.
+//
+// Replaces, for all users at once, the vectorised NumPy prologue of Dataset.compute_channels:
+//   _rotate_angles_batch        geometry.py:244-319   (via dataset.py:310-356)
+//   _apply_FoV_batch            geometry.py:162-195   (via dataset.py:461-512)
+//   dbw2watt + AntennaPattern   generator_utils.py:35, ant_patterns.py:21-71, 145-168
+//   _compute_num_paths / _los   dataset.py:569-619
+//   the k-independent part of OFDM_PathGenerator.generate   channel.py:182-192
+//   the array-response phase    geometry.py:85-102
+// and emits per-path records (dmx_common.h) with the contributing paths compacted to the front
+// of each user's row (wave ballot + prefix popcount), so stage 2 never touches a dead path.
+//
+// Numerics follow the reference's dtype flow on purpose (DESIGN.md "numerics"): deg2rad in
+// float32, sin/cos of the zenith angle rounded to float32, everything touching the rotation in
+// float64, tau/Ts as a float32 division.  This file is compiled with -ffp-contract=off so the
+// float64 expressions associate exactly as NumPy evaluates them.  HBM traffic is ~40 B read and
+// ~50 B written per path: noise next to stage 2's output stream, so no tuning beyond coalescing
+// (lane = path => each field is one contiguous row segment per wave).
+#include "dmx_common.h"
+#include <math.h>
+
+namespace dmx {
+
+struct PrepArgs {
+    dmx_rays rays;
+    dmx_side side;
+    WsView ws;
+    // rotation
+    double bsx, csx, bsy, csy, brz;       // sin/cos of BS rotation about x, y; rotation about z (rad)
+    double usx, ucx, usy, ucy, urz;       // same for a constant UE rotation
+    const double* ue_rot_pu;              // [n,3] degrees or nullptr
+    // fov
+    int fov_enabled, bs_restricted, ue_restricted;
+    double bs_fh, bs_fv, ue_fh, ue_fv;    // radians
+    int bs_pat, ue_pat;
+    double bs_spacing, ue_spacing;
+    int P;                                 // paths used for the channel
+    int freq_domain;
+    int n_sc;
+    float ts32;                            // float32(1/bandwidth)
+    int doppler;
+    int rx_filter;
+    double fc;
+};
+
+static constexpr float D2R_F = 0.017453292519943295f;       // float32(pi/180): np.deg2rad on float32
+static constexpr double D2R_D = 0.017453292519943295;       // np.deg2rad on float64
+static constexpr double TWO_PI = 6.283185307179586;
+static constexpr double HALF_PI = 1.5707963267948966;
+static constexpr double LIGHTSPEED = 299792458.0;           // deepmimo_v3/consts.py:112
+
+// geometry.py:284-310 for one path
+__device__ __forceinline__ void rotate_one(float el_deg, float az_deg, double sx, double cx, double sy,
+                                           double cy, double rz, double& th, double& ph) {
+    const float th32 = el_deg * D2R_F;
+    const float ph32 = az_deg * D2R_F;
+    const double st = (double)(float)sin((double)th32);     // np.sin(float32) -> float32
+    const double ct = (double)(float)cos((double)th32);
+    const double d = (double)ph32 - rz;
+    double sd, cd;
+    sincos(d, &sd, &cd);
+    th = acos(cy * cx * ct + st * (sy * cx * cd - sx * sd));
+    const double re = cy * st * cd - sy * ct;
+    const double im = cy * sx * ct + st * (sy * sx * cd + cx * sd);
+    ph = atan2(im, re);
+}
+
+// np.mod(x, 2pi): result takes the sign of the divisor
+__device__ __forceinline__ double pymod_2pi(double x) {
+    double m = fmod(x, TWO_PI);
+    if (m != 0.0) { if (m < 0.0) m += TWO_PI; } else { m = 0.0; }
+    return m;
+}
+
+// geometry.py:180-193
+__device__ __forceinline__ bool in_fov(double th, double ph, double fh, double fv) {
+    const double t = pymod_2pi(th), p = pymod_2pi(ph);
+    const bool az = (p <= 0 + fh / 2) || (p >= TWO_PI - fh / 2);
+    const bool el = (t <= HALF_PI + fv / 2) && (t >= HALF_PI - fv / 2);
+    return az && el;
+}
+
+// ant_patterns.py:34-71 (NaN -> 0)
+__device__ __forceinline__ double dipole_gain(double th) {
+    const double s = sin(th);
+    if (!(fabs(s) > 1e-10)) return 0.0;
+    const double c = cos(HALF_PI * cos(th));
+    return 1.643 * (c * c / s);
+}
+
+__device__ __forceinline__ uint32_t float_order_key(float f) {
+    uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void k1_path_prep(PrepArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= a.rays.n_ue) return;                           // wave-uniform
+    const dmx_rays& r = a.rays;
+    const int L = r.n_paths;
+    const size_t row = (size_t)u * (size_t)r.ld;
+    const size_t srow = (size_t)u * (size_t)L;              // dense side-product rows
+    const size_t wrow = (size_t)u * (size_t)a.P;
+
+    double usx = a.usx, ucx = a.ucx, usy = a.usy, ucy = a.ucy, urz = a.urz;
+    if (a.ue_rot_pu) {                                      // per-user rotation in degrees (dataset.py:329-338)
+        const double rx = a.ue_rot_pu[3 * u + 0] * D2R_D, ry = a.ue_rot_pu[3 * u + 1] * D2R_D;
+        urz = a.ue_rot_pu[3 * u + 2] * D2R_D;
+        sincos(rx, &usx, &ucx);
+        sincos(ry, &usy, &ucy);
+    }
+    const bool iso = (a.bs_pat == DMX_PATTERN_ISOTROPIC) && (a.ue_pat == DMX_PATTERN_ISOTROPIC);
+    const float nan32 = __int_as_float(0x7fc00000);
+    const double nan64 = (double)nan32;
+
+    int keep_base = 0, count_paths = 0;
+    bool has_fov_path = false;
+    float first_inter = nan32;
+    float maxd = -INFINITY;
+    bool any_delay = false;
+
+    for (int j0 = 0; j0 < L; j0 += 64) {
+        const int j = j0 + lane;
+        const bool in = j < L;
+        const float power = in ? r.power[row + j] : nan32;
+        const float phase = in ? r.phase[row + j] : nan32;
+        const float delay = in ? r.delay[row + j] : nan32;
+        const float aoa_az = in ? r.aoa_az[row + j] : nan32;
+        const float aoa_el = in ? r.aoa_el[row + j] : nan32;
+        const float aod_az = in ? r.aod_az[row + j] : nan32;
+        const float aod_el = in ? r.aod_el[row + j] : nan32;
+        const float inter = in ? r.inter[row + j] : nan32;
+
+        double th_t, ph_t, th_r, ph_r;
+        rotate_one(aod_el, aod_az, a.bsx, a.csx, a.bsy, a.csy, a.brz, th_t, ph_t);
+        rotate_one(aoa_el, aoa_az, usx, ucx, usy, ucy, urz, th_r, ph_r);
+        if (in) {
+            if (a.side.aod_el_rot) a.side.aod_el_rot[srow + j] = th_t;
+            if (a.side.aod_az_rot) a.side.aod_az_rot[srow + j] = ph_t;
+            if (a.side.aoa_el_rot) a.side.aoa_el_rot[srow + j] = th_r;
+            if (a.side.aoa_az_rot) a.side.aoa_az_rot[srow + j] = ph_r;
+        }
+
+        // field of view (dataset.py:493-511): outside -> angles become NaN
+        bool mask = true;
+        if (a.fov_enabled) {
+            if (a.bs_restricted) mask = mask && in_fov(th_t, ph_t, a.bs_fh, a.bs_fv);
+            if (a.ue_restricted) mask = mask && in_fov(th_r, ph_r, a.ue_fh, a.ue_fv);
+            mask = mask && in;
+            if (in && a.side.fov_mask) a.side.fov_mask[srow + j] = mask ? 1 : 0;
+            if (!mask) { th_t = nan64; ph_t = nan64; th_r = nan64; ph_r = nan64; }
+            const unsigned long long mb = __ballot(mask);
+            if (!has_fov_path && mb != 0ull) {               // first in-FoV path (dataset.py:594-598)
+                has_fov_path = true;
+                first_inter = __shfl(inter, __ffsll((long long)mb) - 1);
+            }
+        } else if (j0 == 0) {
+            first_inter = __shfl(inter, 0);                  // dataset.py:602
+        }
+        count_paths += __popcll(__ballot(in && !isnan(ph_r)));   // dataset.py:616-619
+
+        // powers (generator_utils.py:35, ant_patterns.py:167-168)
+        const float p10 = power / 10.0f;
+        const float pl = (float)pow(10.0, (double)p10);
+        double pw;
+        if (iso) {
+            pw = (double)pl;
+        } else {
+            const double gt = a.bs_pat == DMX_PATTERN_HALFWAVE_DIPOLE ? dipole_gain(th_t) : 1.0;
+            const double gr = a.ue_pat == DMX_PATTERN_HALFWAVE_DIPOLE ? dipole_gain(th_r) : 1.0;
+            pw = (double)pl * (gt * gr);
+        }
+        if (in) {
+            if (a.side.power_linear) a.side.power_linear[srow + j] = pl;
+            if (a.side.power_linear_ant_gain) a.side.power_linear_ant_gain[srow + j] = pw;
+        }
+
+        // per-path record for the first P paths (dataset.py:258-261)
+        const bool used = in && j < a.P;
+        if (used && !isnan(delay)) { maxd = fmaxf(maxd, delay); any_delay = true; }
+        const bool valid = used && !isnan(pw);               // channel.py:260
+        const float ph32 = phase * D2R_F;                    // np.deg2rad(float32)
+        const float e_re = (float)cos((double)ph32), e_im = (float)sin((double)ph32);   // complex64 exp
+        const bool ang_ok = !isnan(th_t) && !isnan(th_r);    // geometry.py:65 zeroes NaN-zenith columns
+        float c_re, c_im, dn = 0.0f;
+        bool keep;
+        if (a.freq_domain) {
+            dn = delay / a.ts32;                             // float32 / float32 (channel.py:183)
+            double pwc = pw;
+            if (dn >= (float)a.n_sc) { pwc = 0.0; dn = (float)a.n_sc; }   // channel.py:187-189
+            if (iso) {
+                const float amp = sqrtf((float)pwc / (float)a.n_sc);      // float32 (channel.py:192)
+                c_re = amp * e_re; c_im = amp * e_im;
+            } else {
+                const double amp = sqrt(pwc / (double)a.n_sc);
+                c_re = (float)(amp * (double)e_re); c_im = (float)(amp * (double)e_im);
+            }
+            if (a.doppler && !a.rx_filter && r.doppler_vel && r.doppler_acc) {   // construct_deepmimo.py:267-280
+                const double v = in ? (double)r.doppler_vel[row + j] : 0.0;
+                const double ac = in ? (double)r.doppler_acc[row + j] : 0.0;
+                const double tau = (double)delay;
+                const double arg = -TWO_PI * a.fc * (v * tau / LIGHTSPEED + ac * (tau * tau) / (2.0 * LIGHTSPEED));
+                double sd, cd;
+                sincos(arg, &sd, &cd);
+                const float nr = (float)((double)c_re * cd - (double)c_im * sd);
+                const float ni = (float)((double)c_re * sd + (double)c_im * cd);
+                c_re = nr; c_im = ni;
+            }
+            // nansum (channel.py:283): a path with any NaN factor contributes nothing
+            keep = valid && ang_ok && !isnan(ph_t) && !isnan(ph_r) && !isnan(c_re) && !isnan(c_im) && !isnan(dn) &&
+                   (c_re != 0.0f || c_im != 0.0f);          // clipped / zero-gain paths add exactly 0
+        } else {
+            if (iso) {
+                const float amp = sqrtf((float)pw);                        // channel.py:286
+                c_re = amp * e_re; c_im = amp * e_im;
+            } else {
+                const double amp = sqrt(pw);
+                c_re = (float)(amp * (double)e_re); c_im = (float)(amp * (double)e_im);
+            }
+            if (!ang_ok) { c_re *= 0.0f; c_im *= 0.0f; }                   // zero array response, NaN stays NaN
+            keep = valid;                                                  // slot even if coefficient is 0
+        }
+        double ty = 0.0, tz = 0.0, ry = 0.0, rz = 0.0;
+        if (ang_ok) {
+            ty = a.bs_spacing * (sin(th_t) * sin(ph_t)); tz = a.bs_spacing * cos(th_t);
+            ry = a.ue_spacing * (sin(th_r) * sin(ph_r)); rz = a.ue_spacing * cos(th_r);
+        }
+        const unsigned long long kb = __ballot(keep);
+        if (keep) {
+            const int slot = keep_base + __popcll(kb & ((1ull << lane) - 1ull));
+            a.ws.c_re[wrow + slot] = c_re; a.ws.c_im[wrow + slot] = c_im; a.ws.dn[wrow + slot] = dn;
+            a.ws.tx_y[wrow + slot] = ty; a.ws.tx_z[wrow + slot] = tz;
+            a.ws.rx_y[wrow + slot] = ry; a.ws.rx_z[wrow + slot] = rz;
+            const bool dop = a.doppler && r.doppler_vel && r.doppler_acc;
+            a.ws.dop_v[wrow + slot] = dop ? r.doppler_vel[row + j] : 0.0f;
+            a.ws.dop_a[wrow + slot] = dop ? r.doppler_acc[row + j] : 0.0f;
+        }
+        keep_base += __popcll(kb);
+    }
+
+    // wave reductions
+    for (int off = 32; off > 0; off >>= 1) maxd = fmaxf(maxd, __shfl_xor(maxd, off));
+    const bool anyd = __ballot(any_delay) != 0ull;
+    if (lane == 0) {
+        a.ws.n_keep[u] = keep_base;
+        if (a.side.num_paths) a.side.num_paths[u] = count_paths;
+        if (a.side.los) {
+            const bool has = a.fov_enabled ? has_fov_path : (count_paths > 0);
+            a.side.los[u] = has ? ((first_inter == 0.0f) ? 1 : 0) : -1;    // dataset.py:604-609
+        }
+        if (a.side.max_delay_key && anyd) atomicMax(a.side.max_delay_key, float_order_key(maxd));
+    }
+}
+
+int launch_path_prep(const dmx_rays& rays, const dmx_params& prm, const WsView& ws, const dmx_side& side,
+                     hipStream_t stream) {
+    PrepArgs a;
+    a.rays = rays; a.side = side; a.ws = ws;
+    a.bsx = sin(prm.bs_rotation[0]); a.csx = cos(prm.bs_rotation[0]);
+    a.bsy = sin(prm.bs_rotation[1]); a.csy = cos(prm.bs_rotation[1]);
+    a.brz = prm.bs_rotation[2];
+    a.usx = sin(prm.ue_rotation[0]); a.ucx = cos(prm.ue_rotation[0]);
+    a.usy = sin(prm.ue_rotation[1]); a.ucy = cos(prm.ue_rotation[1]);
+    a.urz = prm.ue_rotation[2];
+    a.ue_rot_pu = prm.ue_rotation_per_user;
+    a.fov_enabled = prm.fov_enabled; a.bs_restricted = prm.bs_fov_restricted; a.ue_restricted = prm.ue_fov_restricted;
+    a.bs_fh = prm.bs_fov[0]; a.bs_fv = prm.bs_fov[1]; a.ue_fh = prm.ue_fov[0]; a.ue_fv = prm.ue_fov[1];
+    a.bs_pat = prm.bs_pattern; a.ue_pat = prm.ue_pattern;
+    a.bs_spacing = prm.bs_spacing; a.ue_spacing = prm.ue_spacing;
+    a.P = ws.P; a.freq_domain = prm.freq_domain; a.n_sc = prm.n_subcarriers;
+    a.ts32 = (float)(1.0 / prm.bandwidth);
+    a.doppler = prm.enable_doppler; a.fc = prm.carrier_freq; a.rx_filter = prm.rx_filter && prm.freq_domain;
+    if (rays.n_ue == 0) return DMX_OK;
+    const unsigned grid = (unsigned)((rays.n_ue + 3) / 4);
+    hipLaunchKernelGGL(k1_path_prep, dim3(grid), dim3(256), 0, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("k1_path_prep launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
+    return DMX_OK;
+}
+
+}  // namespace dmx

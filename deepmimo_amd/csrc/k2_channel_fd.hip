@@ -1,0 +1,244 @@
+// Stage 2, frequency domain - fp32 vector kernel (variant 1).
+//
+// out[u, rx, tx, k] = sum_l a_rx[rx,l] * a_tx[tx,l] * c_l * exp(-j 2pi dn_l sc_k / N)
+// replaces Dataset._compute_array_response_product (dataset.py:398-417; the reference materialises a
+// complex128 [N, M_rx, M_tx, L] tensor - never built here) and the per-user loop of
+// _generate_MIMO_channel (channel.py:264-284; complex128 broadcast product + nansum).
+//
+// Mapping: one 256-thread workgroup per user.  Per user the two small factor tables
+//   b_rx[r][l] = c_l * a_rx[r,l]   and   a_tx[t][l]
+// are built once in LDS (sincos of a float64-range-reduced phase, so element-index multiples of the
+// per-path step cost no accuracy).  Each wave then owns 64-subcarrier chunks: lane = subcarrier, so
+// the lane keeps its L subcarrier phasors g_l = exp(-j 2pi frac(dn_l*k/N)) in registers (the
+// frac() is done in float64: dn*k needs 34 bits, SURVEY finding 6), forms t_l = b_rx[r][l]*g_l per
+// receive element and walks the transmit elements with 4*L FMAs per output; the a_tx row is a
+// wave-uniform LDS broadcast read, shared by RB receive elements to halve LDS traffic.
+// Stores are 8 B/lane, 512 B contiguous per wave instruction (K is the fastest output index).
+//
+// Roofline: 8*M_rx*M_tx*K output bytes per user vs 8*L flop per output element: at L = 25 this is
+// at the fp32 ridge of the chip (25 flop/B), so this kernel is VALU-bound; the MFMA variant
+// (k2_channel_fd_mfma.hip) removes that bound.  This one stays as the exact-fp32, any-shape path.
+#include "dmx_common.h"
+
+namespace dmx {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct FdArgs {
+    int64_t user_begin;
+    int m_rx, m_tx, ue_mh, bs_mh;
+    int K;
+    const int32_t* sc;
+    double inv_n;
+    int txt;        // transmit elements per LDS tile
+    const float2* gtab;   // rx_filter variant: precomputed path gains [user_count, P, K] (k3_lpf_gains.hip)
+};
+
+// Everything one workgroup does for one user with LPA (multiple of 4) path slots; slots beyond the
+// user's n_act paths hold zero table entries, so the unrolled loops need no guards.
+template <int LPA, int RB, bool GLOAD>
+__device__ __forceinline__ void fd_user(const WsView& ws, const FdArgs& a, float2* __restrict__ o, int64_t u,
+                                        int n_act, unsigned char* smem) {
+    double* q = reinterpret_cast<double*>(smem);                 // [LPA]  dn_l / N
+    float* brx = reinterpret_cast<float*>(q + LPA);             // [m_rx][2*LPA]
+    float* atx = brx + (size_t)a.m_rx * 2 * LPA;                // [txt][2*LPA]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t rb = (size_t)u * ws.P;
+
+    if (tid < LPA) q[tid] = tid < n_act ? (double)ws.dn[rb + tid] * a.inv_n : 0.0;
+    for (int i = tid; i < a.m_rx * LPA; i += 256) {
+        const int r = i / LPA, l = i - r * LPA;
+        float re = 0.f, im = 0.f;
+        if (l < n_act) {
+            const int y = r % a.ue_mh, z = r / a.ue_mh;
+            float s, c;
+            sincos_rev(frac_rev((double)y * ws.rx_y[rb + l] + (double)z * ws.rx_z[rb + l]), s, c);
+            // with precomputed gains the path coefficient c_l is already inside g
+            const float cr = GLOAD ? 1.0f : ws.c_re[rb + l], ci = GLOAD ? 0.0f : ws.c_im[rb + l];
+            re = cr * c - ci * s;
+            im = cr * s + ci * c;
+        }
+        brx[(size_t)r * 2 * LPA + 2 * l] = re;
+        brx[(size_t)r * 2 * LPA + 2 * l + 1] = im;
+    }
+
+    const int nchunks = (a.K + 63) >> 6;
+    for (int tx0 = 0; tx0 < a.m_tx; tx0 += a.txt) {
+        const int ntx = (a.m_tx - tx0) < a.txt ? (a.m_tx - tx0) : a.txt;
+        __syncthreads();                                         // previous tile fully consumed
+        for (int i = tid; i < ntx * LPA; i += 256) {
+            const int t = i / LPA, l = i - t * LPA;
+            float s = 0.f, c = 0.f;
+            if (l < n_act) {
+                const int m = tx0 + t, y = m % a.bs_mh, z = m / a.bs_mh;
+                sincos_rev(frac_rev((double)y * ws.tx_y[rb + l] + (double)z * ws.tx_z[rb + l]), s, c);
+            }
+            atx[(size_t)t * 2 * LPA + 2 * l] = c;
+            atx[(size_t)t * 2 * LPA + 2 * l + 1] = s;
+        }
+        __syncthreads();
+
+        for (int ch = wave; ch < nchunks; ch += 4) {
+            const int kidx = (ch << 6) + lane;
+            const bool kok = kidx < a.K;
+            const double kk = (double)(kok ? a.sc[kidx] : 0);
+            float g_re[LPA], g_im[LPA];
+#pragma unroll
+            for (int l = 0; l < LPA; ++l) {
+                if constexpr (GLOAD) {
+                    float2 v = make_float2(0.f, 0.f);
+                    if (kok && l < n_act) v = a.gtab[((size_t)blockIdx.x * ws.P + l) * a.K + kidx];
+                    g_re[l] = v.x; g_im[l] = v.y;
+                } else {
+                    float s, c;
+                    sincos_rev(frac_rev(q[l] * kk), s, c);      // exp(-j 2pi x) = cos - j sin
+                    g_re[l] = c; g_im[l] = -s;
+                    __builtin_amdgcn_sched_barrier(0);           // one phasor at a time: keeps live temporaries low
+                }
+            }
+            for (int rx0 = 0; rx0 < a.m_rx; rx0 += RB) {
+                v2f t[RB][LPA];                                  // t_l = b_rx[r][l] * g_l as (re, im) pairs
+#pragma unroll
+                for (int b = 0; b < RB; ++b) {
+                    const int r = (rx0 + b) < a.m_rx ? (rx0 + b) : (a.m_rx - 1);
+                    const float4* brow = reinterpret_cast<const float4*>(brx + (size_t)r * 2 * LPA);
+#pragma unroll
+                    for (int l = 0; l < LPA; l += 2) {
+                        const float4 v = brow[l / 2];
+                        t[b][l].x = v.x * g_re[l] - v.y * g_im[l];
+                        t[b][l].y = v.x * g_im[l] + v.y * g_re[l];
+                        t[b][l + 1].x = v.z * g_re[l + 1] - v.w * g_im[l + 1];
+                        t[b][l + 1].y = v.z * g_im[l + 1] + v.w * g_re[l + 1];
+                    }
+                }
+                for (int tx = 0; tx < ntx; ++tx) {
+                    const float4* arow = reinterpret_cast<const float4*>(atx + (size_t)tx * 2 * LPA);
+                    // H = sum (ar + j ai)(tr + j ti): accA += ar*(tr,ti), accB += ai*(tr,ti);
+                    // re = accA.x - accB.y, im = accA.y + accB.x  -> two packed FMAs per path, no swapped copies.
+                    v2f accA[RB], accB[RB];
+#pragma unroll
+                    for (int b = 0; b < RB; ++b) { accA[b] = v2f{0.f, 0.f}; accB[b] = v2f{0.f, 0.f}; }
+#pragma unroll
+                    for (int l = 0; l < LPA; l += 2) {
+                        const float4 v = arow[l / 2];
+#pragma unroll
+                        for (int b = 0; b < RB; ++b) {
+                            accA[b] = __builtin_elementwise_fma(v2f{v.x, v.x}, t[b][l], accA[b]);
+                            accB[b] = __builtin_elementwise_fma(v2f{v.y, v.y}, t[b][l], accB[b]);
+                            accA[b] = __builtin_elementwise_fma(v2f{v.z, v.z}, t[b][l + 1], accA[b]);
+                            accB[b] = __builtin_elementwise_fma(v2f{v.w, v.w}, t[b][l + 1], accB[b]);
+                        }
+                    }
+                    if (kok) {
+#pragma unroll
+                        for (int b = 0; b < RB; ++b) {
+                            if (rx0 + b < a.m_rx)
+                                o[((size_t)(rx0 + b) * a.m_tx + (tx0 + tx)) * a.K + kidx] =
+                                    make_float2(accA[b].x - accB[b].y, accA[b].y + accB[b].x);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// LPMAX = slots the launch provides LDS/registers for (>= P); each user runs the smallest body
+// that holds its n_act compacted paths (real ray-traced users have far fewer than P paths).
+template <int LPMAX, int RB, bool GLOAD>
+__global__ __launch_bounds__(256, 2) void k2_fd_valu(WsView ws, FdArgs a, float2* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int64_t u = a.user_begin + blockIdx.x;
+    const size_t per_user = (size_t)a.m_rx * a.m_tx * a.K;
+    float2* __restrict__ o = out + (size_t)blockIdx.x * per_user;
+    int n_act = ws.n_keep[u];
+    n_act = n_act < LPMAX ? n_act : LPMAX;
+    if (n_act == 0) {                                            // channel.py:270-271: stays all-zero
+        for (size_t i = tid; i < per_user; i += 256) o[i] = make_float2(0.f, 0.f);
+        return;
+    }
+    const int n4 = (n_act + 3) >> 2;
+    if constexpr (LPMAX >= 32) { if (n4 == 8) { fd_user<32, RB, GLOAD>(ws, a, o, u, n_act, smem); return; } }
+    if constexpr (LPMAX >= 28) { if (n4 == 7) { fd_user<28, RB, GLOAD>(ws, a, o, u, n_act, smem); return; } }
+    if constexpr (LPMAX >= 24) { if (n4 == 6) { fd_user<24, RB, GLOAD>(ws, a, o, u, n_act, smem); return; } }
+    if constexpr (LPMAX >= 20) { if (n4 == 5) { fd_user<20, RB, GLOAD>(ws, a, o, u, n_act, smem); return; } }
+    if constexpr (LPMAX >= 16) { if (n4 == 4) { fd_user<16, RB, GLOAD>(ws, a, o, u, n_act, smem); return; } }
+    if constexpr (LPMAX >= 12) { if (n4 == 3) { fd_user<12, RB, GLOAD>(ws, a, o, u, n_act, smem); return; } }
+    if constexpr (LPMAX >= 8) { if (n4 == 2) { fd_user<8, RB, GLOAD>(ws, a, o, u, n_act, smem); return; } }
+    fd_user<4, RB, GLOAD>(ws, a, o, u, n_act, smem);
+}
+
+template <int LP, int RB, bool GLOAD = false>
+static int launch_valu(const WsView& ws, const FdArgs& a0, int64_t user_count, float2* out, hipStream_t stream) {
+    FdArgs a = a0;
+    const size_t fixed = (size_t)LP * 8 + (size_t)a.m_rx * 2 * LP * 4;
+    const size_t budget = 64 * 1024;
+    if (fixed + (size_t)2 * LP * 4 > budget) {
+        set_error("UE array of %d elements does not fit the LDS tables (max about %d)", a.m_rx, (int)(budget / (8 * LP)) - 2);
+        return DMX_ERR_SHAPE;
+    }
+    int txt = (int)((budget - fixed) / ((size_t)2 * LP * 4));
+    if (txt > a.m_tx) txt = a.m_tx;
+    a.txt = txt;
+    const size_t smem = fixed + (size_t)txt * 2 * LP * 4;
+    hipLaunchKernelGGL((k2_fd_valu<LP, RB, GLOAD>), dim3((unsigned)user_count), dim3(256), smem, stream, ws, a, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("k2_fd_valu launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
+    return DMX_OK;
+}
+
+static int launch_fd_valu_any(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
+                              const float2* gtab, float2* out, hipStream_t stream) {
+    FdArgs a;
+    a.user_begin = user_begin;
+    a.m_rx = prm.ue_shape[0] * prm.ue_shape[1];
+    a.m_tx = prm.bs_shape[0] * prm.bs_shape[1];
+    a.ue_mh = prm.ue_shape[0];
+    a.bs_mh = prm.bs_shape[0];
+    a.K = prm.n_selected;
+    a.sc = prm.selected_subcarriers;
+    a.inv_n = 1.0 / (double)prm.n_subcarriers;
+    a.txt = 0;
+    a.gtab = gtab;
+    const int P = ws.P;
+    // RB = receive elements sharing one a_tx row read.  2 halves the LDS traffic but doubles the t
+    // registers; beyond 16 path slots that would spill, so the long-path bodies use RB = 1.
+    const bool rb2 = a.m_rx >= 2;
+    if (gtab) {
+        if (P <= 8) return launch_valu<8, 1, true>(ws, a, user_count, out, stream);
+        if (P <= 16) return launch_valu<16, 1, true>(ws, a, user_count, out, stream);
+        if (P <= 28) return launch_valu<28, 1, true>(ws, a, user_count, out, stream);
+        if (P <= 32) return launch_valu<32, 1, true>(ws, a, user_count, out, stream);
+    } else {
+        if (P <= 8) return rb2 ? launch_valu<8, 2>(ws, a, user_count, out, stream) : launch_valu<8, 1>(ws, a, user_count, out, stream);
+        if (P <= 16) return rb2 ? launch_valu<16, 2>(ws, a, user_count, out, stream) : launch_valu<16, 1>(ws, a, user_count, out, stream);
+        if (P <= 28) return launch_valu<28, 1>(ws, a, user_count, out, stream);
+        if (P <= 32) return launch_valu<32, 1>(ws, a, user_count, out, stream);
+    }
+    set_error("num_paths = %d exceeds the %d paths the frequency-domain kernel supports", P, 32);
+    return DMX_ERR_SHAPE;
+}
+
+int launch_channels_fd_mfma(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
+                            float2* out, hipStream_t stream);
+bool fd_mfma_supported(const dmx_params& prm, const WsView& ws);
+
+int launch_channels_fd(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
+                       float2* out, int variant, hipStream_t stream) {
+    if (user_count == 0) return DMX_OK;
+    if (variant == 2 && !fd_mfma_supported(prm, ws)) {
+        set_error("MFMA variant does not support this shape");
+        return DMX_ERR_SHAPE;
+    }
+    if (variant == 2 || (variant == 0 && fd_mfma_supported(prm, ws)))
+        return launch_channels_fd_mfma(prm, ws, user_begin, user_count, out, stream);
+    return launch_fd_valu_any(prm, ws, user_begin, user_count, nullptr, out, stream);
+}
+
+int launch_channels_fd_lpf_contract(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
+                                    const float2* gtab, float2* out, hipStream_t stream) {
+    return launch_fd_valu_any(prm, ws, user_begin, user_count, gtab, out, stream);
+}
+
+}  // namespace dmx

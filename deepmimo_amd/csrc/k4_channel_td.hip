@@ -1,0 +1,58 @@
+// Stage 2, time domain: out[u, rx, tx, s] = a_rx[rx,s] * a_tx[tx,s] * sqrt(p_s) e^{j phase_s}
+// for the s-th valid path of user u (valid paths compacted to the front), zero for the remaining
+// slots.  Replaces the TD branch of _generate_MIMO_channel (channel.py:285-287).
+//
+// The output is only [M_rx, M_tx, P] per user (P <= 25), so this is a plain HBM-store-bound
+// elementwise kernel: thread = output element (slot fastest => contiguous complex64 stores), the
+// element's phase is the float64 sum of its four index x step products, range-reduced once.
+#include "dmx_common.h"
+
+namespace dmx {
+
+struct TdArgs {
+    int64_t user_begin;
+    int m_rx, m_tx, ue_mh, bs_mh;
+};
+
+__global__ __launch_bounds__(256) void k4_td(WsView ws, TdArgs a, float2* __restrict__ out) {
+    const int64_t u = a.user_begin + blockIdx.x;
+    const int P = ws.P;
+    const size_t per_user = (size_t)a.m_rx * a.m_tx * P;
+    float2* __restrict__ o = out + (size_t)blockIdx.x * per_user;
+    const int n_keep = ws.n_keep[u];
+    const size_t rb = (size_t)u * P;
+    for (size_t i = threadIdx.x; i < per_user; i += 256) {
+        const int s = (int)(i % P);
+        const int m = (int)((i / P) % a.m_tx);
+        const int r = (int)(i / ((size_t)P * a.m_tx));
+        float2 v = make_float2(0.f, 0.f);
+        if (s < n_keep) {
+            const int ty = m % a.bs_mh, tz = m / a.bs_mh, ry = r % a.ue_mh, rz = r / a.ue_mh;
+            const double ph = (double)ty * ws.tx_y[rb + s] + (double)tz * ws.tx_z[rb + s] +
+                              (double)ry * ws.rx_y[rb + s] + (double)rz * ws.rx_z[rb + s];
+            float sn, cs;
+            sincos_rev(frac_rev(ph), sn, cs);
+            const float cr = ws.c_re[rb + s], ci = ws.c_im[rb + s];
+            v.x = cr * cs - ci * sn;
+            v.y = cr * sn + ci * cs;
+        }
+        o[i] = v;
+    }
+}
+
+int launch_channels_td(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
+                       float2* out, hipStream_t stream) {
+    if (user_count == 0 || ws.P == 0) return DMX_OK;
+    TdArgs a;
+    a.user_begin = user_begin;
+    a.m_rx = prm.ue_shape[0] * prm.ue_shape[1];
+    a.m_tx = prm.bs_shape[0] * prm.bs_shape[1];
+    a.ue_mh = prm.ue_shape[0];
+    a.bs_mh = prm.bs_shape[0];
+    hipLaunchKernelGGL(k4_td, dim3((unsigned)user_count), dim3(256), 0, stream, ws, a, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("k4_td launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
+    return DMX_OK;
+}
+
+}  // namespace dmx

@@ -1,0 +1,351 @@
+"""``Dataset`` / ``MacroDataset`` - the drop-in boundary of the channel-generation path.
+
+Mirrors the parts of deepmimo/generator/dataset.py that orchestrate the hot path:
+
+  * dict + attribute access with lazy computed attributes and the alias table
+    (dataset.py:130-182, consts.py:261-322);
+  * ``set_channel_params`` / ``compute_channels`` / ``apply_fov`` and the cache invalidation
+    rules (dataset.py:197-268, 358-378, 423-448, 515-535);
+  * the computed attributes ``los``, ``num_paths``, ``power_linear``, ``_power_linear_ant_gain``,
+    rotated and FoV-filtered angles, ``_fov_mask``, ``channel`` (dataset.py:831-869);
+  * ``MacroDataset`` fan-out (dataset.py:888-998).
+
+Every number those attributes hold is produced on the GPU by the C-ABI library (engine.py ->
+csrc/*.hip); this module is glue (names, caching, dtype of the returned arrays, RNG order for the
+random UE rotation).  There is no NumPy implementation of the channel math in this package.
+
+Deliberate deviation from the reference: ``compute_channels`` re-derives all
+per-path side products from the current parameters on every call, so a changed radiation pattern
+takes effect (the reference only invalidates its ``_power_linear_ant_gain`` cache on a rotation
+or FoV change - dataset.py:213-220 - and would silently reuse the stale array).
+"""
+from __future__ import annotations
+
+import inspect
+from typing import Any, Dict, Optional
+
+import numpy as np
+
+from . import consts as c
+from .channel import ChannelGenParameters
+from .config import config
+from .general_utils import DotDict
+
+SHARED_PARAMS = [c.SCENE_PARAM_NAME, c.MATERIALS_PARAM_NAME, c.LOAD_PARAMS_PARAM_NAME, c.RT_PARAMS_PARAM_NAME]
+
+_ROT_KEYS = (c.AOD_EL_ROT_PARAM_NAME, c.AOD_AZ_ROT_PARAM_NAME, c.AOA_EL_ROT_PARAM_NAME, c.AOA_AZ_ROT_PARAM_NAME)
+_FOV_ANGLE_KEYS = (c.AOD_EL_FOV_PARAM_NAME, c.AOD_AZ_FOV_PARAM_NAME, c.AOA_EL_FOV_PARAM_NAME, c.AOA_AZ_FOV_PARAM_NAME)
+_UE_ROT_RESOLVED = "_ue_rotation_resolved"     # [n_ue, 3] degrees actually used for the cached rotated angles
+
+_engines: Dict[int, Any] = {}
+
+
+def _engine():
+    """Process-wide ChannelEngine for config('gpu_device_id').  Raises when use_gpu is off."""
+    if not config.get("use_gpu", True):
+        raise RuntimeError("deepmimo_amd has no CPU channel-generation path: set dm.config('use_gpu', True).")
+    dev = int(config.get("gpu_device_id", 0))
+    if dev not in _engines:
+        from .engine import ChannelEngine
+        _engines[dev] = ChannelEngine(dev)
+    return _engines[dev]
+
+
+class Dataset(DotDict):
+    """One (TX, RX-set) pair of ray-tracing results plus everything computed from it."""
+
+    def __init__(self, data: Optional[Dict[str, Any]] = None):
+        super().__init__(data or {})
+
+    # -------------------------------------------------------------- lookup chain (dataset.py:130-182)
+    def __getattr__(self, key: str) -> Any:
+        if key.startswith("__"):
+            raise AttributeError(key)
+        try:
+            return self._data[key]
+        except KeyError:
+            return self._resolve_key(key)
+
+    def __getitem__(self, key: str) -> Any:
+        try:
+            return self._data[key]
+        except KeyError:
+            return self._resolve_key(key)
+
+    def _resolve_key(self, key: str) -> Any:
+        resolved = c.DATASET_ALIASES.get(key, key)
+        if resolved != key:
+            key = resolved
+            if key in self._data:
+                return self._data[key]
+        if key in self._computed_attributes:
+            value = getattr(self, self._computed_attributes[key])()
+            if isinstance(value, dict):
+                self.update(value)
+                return self._data[key]
+            self[key] = value
+            return value
+        raise KeyError(key)
+
+    def __dir__(self):
+        return sorted(set(list(super().__dir__()) + list(self._computed_attributes.keys()) +
+                          list(c.DATASET_ALIASES.keys())))
+
+    # -------------------------------------------------------------- channel parameters
+    def set_channel_params(self, params: Optional[ChannelGenParameters] = None):
+        """dataset.py:197-222: validate, store a deep copy, drop rotation-dependent caches when a
+        rotation changed."""
+        if params is None:
+            params = ChannelGenParameters()
+        params.validate(self.n_ue)
+        old = self._data.get(c.CH_PARAMS_PARAM_NAME)
+        self.ch_params = params.deepcopy()
+        if old is not None:
+            rot = c.PARAMSET_ANT_ROTATION
+            if (not np.array_equal(old.bs_antenna[rot], params.bs_antenna[rot]) or
+                    not np.array_equal(old.ue_antenna[rot], params.ue_antenna[rot])):
+                self._clear_cache_rotated_angles()
+        return params
+
+    # -------------------------------------------------------------- GPU passes
+    def _resolved_ue_rotation(self):
+        """Per-user UE rotation in degrees or None for a constant one (dataset.py:327-338).  A (3, 2)
+        array is a [lo, hi] range drawn with the global NumPy RNG, exactly as the reference draws it;
+        the draw is cached with the rotated angles (and dropped with them)."""
+        rot = np.asarray(self.ch_params.ue_antenna[c.PARAMSET_ANT_ROTATION])
+        if rot.ndim == 1 and rot.shape[0] == 3:
+            return None
+        cached = self._data.get(_UE_ROT_RESOLVED)
+        if cached is not None:
+            return cached
+        if rot.ndim == 2 and rot.shape == (3, 2):
+            rot = np.random.uniform(rot[:, 0], rot[:, 1], (self.n_ue, 3))
+        rot = np.ascontiguousarray(rot, dtype=np.float64).reshape(-1, 3)
+        self._data[_UE_ROT_RESOLVED] = rot
+        return rot
+
+    def _carrier_freq(self) -> float:
+        rt = self._data.get(c.RT_PARAMS_PARAM_NAME)
+        try:
+            return float(rt[c.RT_PARAM_FREQUENCY]) if rt is not None else 0.0
+        except Exception:
+            return 0.0
+
+    def _run_prep(self, want_side: bool = True):
+        """Stage 1 on the GPU; refreshes every per-path side product in the cache."""
+        eng = _engine()
+        params = self.ch_params
+        rays = eng.upload_rays(self)
+        prep = eng.prepare(rays, params, bs_fov=self._data.get("bs_fov"), ue_fov=self._data.get("ue_fov"),
+                           ue_rotation_per_user=self._resolved_ue_rotation(), carrier_freq=self._carrier_freq(),
+                           want_side=want_side)
+        if want_side:
+            self._store_side(prep)
+        return eng, prep
+
+    def _store_side(self, prep) -> None:
+        s = prep.side
+        host = {k: (None if v is None else v.cpu().numpy()) for k, v in s.items() if k != "max_delay_key"}
+        mask = None if host["fov_mask"] is None else host["fov_mask"].astype(bool)
+        rot = {c.AOD_EL_ROT_PARAM_NAME: host["aod_el_rot"], c.AOD_AZ_ROT_PARAM_NAME: host["aod_az_rot"],
+               c.AOA_EL_ROT_PARAM_NAME: host["aoa_el_rot"], c.AOA_AZ_ROT_PARAM_NAME: host["aoa_az_rot"]}
+        d = self._data
+        d.update(rot)
+        d[c.FOV_MASK_PARAM_NAME] = mask
+        for k_rot, k_fov in zip(_ROT_KEYS, _FOV_ANGLE_KEYS):                  # dataset.py:506-511
+            d[k_fov] = rot[k_rot] if mask is None else np.where(mask, rot[k_rot], np.nan)
+        d[c.PWR_LINEAR_PARAM_NAME] = host["power_linear"]
+        iso = all(self.ch_params[s_][c.PARAMSET_ANT_RAD_PAT] == c.PARAMSET_ANT_RAD_PAT_VALS[0]
+                  for s_ in (c.PARAMSET_ANT_BS, c.PARAMSET_ANT_UE))
+        g = host["power_linear_ant_gain"]
+        d[c.PWR_LINEAR_ANT_GAIN_PARAM_NAME] = g.astype(np.float32) if iso else g   # float32 * 1.0 stays float32
+        d[c.NUM_PATHS_PARAM_NAME] = host["num_paths"].astype(np.int64)
+        d[c.LOS_PARAM_NAME] = host["los"].astype(np.int64)
+
+    def compute_channels(self, params: Optional[ChannelGenParameters] = None):
+        """dataset.py:224-268.  Returns complex64 [n_ue, M_rx, M_tx, K] (freq_domain) or
+        [n_ue, M_rx, M_tx, num_paths]: a NumPy array by default, the HBM-resident torch tensor when
+        ``config('channel_output') == 'torch'``.  Cached as ``dataset.channel``."""
+        if params is None:
+            params = ChannelGenParameters() if self._data.get(c.CH_PARAMS_PARAM_NAME) is None else self.ch_params
+        self.set_channel_params(params)
+        np.random.seed(1001)                                                   # dataset.py:250
+        eng, prep = self._run_prep(want_side=True)
+        chan = eng.channels(prep, variant=int(config.get("fd_kernel_variant", 0)))
+        ofdm = params[c.PARAMSET_OFDM]
+        if params[c.PARAMSET_FD_CH]:
+            self._warn_symbol_duration(eng.max_delay(prep), ofdm)
+        out = chan if config.get("channel_output", "numpy") == "torch" else chan.cpu().numpy()
+        self[c.CHANNEL_PARAM_NAME] = out
+        return out
+
+    @staticmethod
+    def _warn_symbol_duration(max_delay: float, ofdm) -> None:
+        """The reference's clipping warning (channel.py:228-250), fed by the device-side max."""
+        n_sc, bw = ofdm[c.PARAMSET_OFDM_SC_NUM], ofdm[c.PARAMSET_OFDM_BANDWIDTH]
+        symbol = n_sc / bw
+        if not (max_delay > symbol):
+            return
+        print("\nWarning: Some path delays exceed OFDM symbol duration")
+        print("-" * 50)
+        print("OFDM Configuration:")
+        print(f"- Number of subcarriers (N): {n_sc}")
+        print(f"- Bandwidth (B): {bw/1e6:.1f} MHz")
+        print(f"- Subcarrier spacing (Δf = B/N): {bw/n_sc/1e3:.1f} kHz")
+        print(f"- Symbol duration (T = 1/Δf = N/B): {symbol*1e6:.1f} μs")
+        print("\nPath Information:")
+        print(f"- Maximum path delay: {max_delay*1e6:.1f} μs")
+        print(f"- Excess delay: {(max_delay - symbol)*1e6:.1f} μs")
+        print("\nPaths arriving after the symbol duration will be clipped.")
+        print("To avoid clipping, either:")
+        print("1. Increase the number of subcarriers (N)")
+        print("2. Decrease the bandwidth (B)")
+        print(f"3. Switch to time-domain channel generation (set ch_params['{c.PARAMSET_FD_CH}'] = 0)")
+        print("-" * 50)
+
+    # -------------------------------------------------------------- lazily computed attributes
+    def _side(self, key):
+        """Run stage 1 if `key` is not cached yet, then return it (all side products land together)."""
+        if key not in self._data:
+            _ = self.ch_params                                              # resolves defaults if never set
+            self._run_prep(want_side=True)
+        return self._data[key]
+
+    def _compute_rotated_angles(self) -> Dict[str, np.ndarray]:
+        self._side(c.AOD_EL_ROT_PARAM_NAME)
+        return {k: self._data[k] for k in _ROT_KEYS}
+
+    def _compute_fov(self) -> Dict[str, Any]:
+        self._side(c.FOV_MASK_PARAM_NAME)
+        return {k: self._data[k] for k in (c.FOV_MASK_PARAM_NAME,) + _FOV_ANGLE_KEYS}
+
+    def _compute_num_paths(self) -> np.ndarray:
+        return self._side(c.NUM_PATHS_PARAM_NAME)
+
+    def _compute_los(self) -> np.ndarray:
+        return self._side(c.LOS_PARAM_NAME)
+
+    def _compute_power_linear(self) -> np.ndarray:
+        return self._side(c.PWR_LINEAR_PARAM_NAME)
+
+    def _compute_power_linear_ant_gain(self) -> np.ndarray:
+        return self._side(c.PWR_LINEAR_ANT_GAIN_PARAM_NAME)
+
+    def _compute_n_ue(self) -> int:
+        return self.rx_pos.shape[0]                                          # dataset.py:657-659
+
+    def _compute_distances(self) -> np.ndarray:
+        return np.linalg.norm(self.rx_pos - self.tx_pos, axis=1)             # dataset.py:661-663
+
+    def _compute_inter_int(self) -> np.ndarray:
+        v = np.array(self.inter, copy=True)                                  # dataset.py:629-637
+        v[np.isnan(v)] = -1
+        return v.astype(int)
+
+    # -------------------------------------------------------------- field of view (dataset.py:423-448)
+    def apply_fov(self, bs_fov: np.ndarray = np.array([360, 180]), ue_fov: np.ndarray = np.array([360, 180])) -> None:
+        self._clear_cache_fov()
+        self.bs_fov = bs_fov
+        self.ue_fov = ue_fov
+
+    def _clear_cache_fov(self) -> None:
+        """dataset.py:515-535"""
+        for k in (c.FOV_MASK_PARAM_NAME, c.NUM_PATHS_PARAM_NAME, c.LOS_PARAM_NAME, c.CHANNEL_PARAM_NAME,
+                  c.PWR_LINEAR_ANT_GAIN_PARAM_NAME) + _FOV_ANGLE_KEYS:
+            self._data.pop(k, None)
+
+    def _clear_cache_rotated_angles(self) -> None:
+        """dataset.py:358-378"""
+        for k in _ROT_KEYS + (_UE_ROT_RESOLVED,):
+            self._data.pop(k, None)
+        self._clear_cache_fov()
+
+    # -------------------------------------------------------------- orientation helpers (dataset.py:274-308)
+    @property
+    def tx_ori(self) -> np.ndarray:
+        return self.ch_params["bs_antenna"]["rotation"] * np.pi / 180
+
+    @property
+    def bs_ori(self) -> np.ndarray:
+        return self.tx_ori
+
+    @property
+    def rx_ori(self) -> np.ndarray:
+        return self.ch_params["ue_antenna"]["rotation"] * np.pi / 180
+
+    @property
+    def ue_ori(self) -> np.ndarray:
+        return self.rx_ori
+
+    _computed_attributes = {
+        c.N_UE_PARAM_NAME: "_compute_n_ue",
+        c.NUM_PATHS_PARAM_NAME: "_compute_num_paths",
+        c.DIST_PARAM_NAME: "_compute_distances",
+        c.CHANNEL_PARAM_NAME: "compute_channels",
+        c.LOS_PARAM_NAME: "_compute_los",
+        c.CH_PARAMS_PARAM_NAME: "set_channel_params",
+        c.PWR_LINEAR_PARAM_NAME: "_compute_power_linear",
+        c.AOA_AZ_ROT_PARAM_NAME: "_compute_rotated_angles",
+        c.AOA_EL_ROT_PARAM_NAME: "_compute_rotated_angles",
+        c.AOD_AZ_ROT_PARAM_NAME: "_compute_rotated_angles",
+        c.AOD_EL_ROT_PARAM_NAME: "_compute_rotated_angles",
+        "fov": "_compute_fov",
+        c.FOV_MASK_PARAM_NAME: "_compute_fov",
+        c.AOA_AZ_FOV_PARAM_NAME: "_compute_fov",
+        c.AOA_EL_FOV_PARAM_NAME: "_compute_fov",
+        c.AOD_AZ_FOV_PARAM_NAME: "_compute_fov",
+        c.AOD_EL_FOV_PARAM_NAME: "_compute_fov",
+        c.PWR_LINEAR_ANT_GAIN_PARAM_NAME: "_compute_power_linear_ant_gain",
+        c.INTER_INT_PARAM_NAME: "_compute_inter_int",
+    }
+
+
+class MacroDataset:
+    """List of Datasets (one per TX / RX-set pair); attribute access and method calls fan out to
+    every child, a single child returns its value unwrapped (dataset.py:888-998)."""
+
+    SINGLE_ACCESS_METHODS = {"info"}
+    PROPAGATE_METHODS = {name for name, _ in inspect.getmembers(Dataset, predicate=inspect.isfunction)
+                         if not name.startswith("__")}
+
+    def __init__(self, datasets=None):
+        self.datasets = datasets if datasets is not None else []
+
+    def _get_single(self, key):
+        if not self.datasets:
+            raise IndexError("MacroDataset is empty")
+        return self.datasets[0][key]
+
+    def __getattr__(self, name):
+        if name in ("datasets",) or name.startswith("__"):
+            raise AttributeError(name)
+        if name in self.PROPAGATE_METHODS:
+            if name in self.SINGLE_ACCESS_METHODS:
+                return lambda *a, **k: getattr(self.datasets[0], name)(*a, **k)
+
+            def fan_out(*a, **k):
+                res = [getattr(d, name)(*a, **k) for d in self.datasets]
+                return res[0] if len(res) == 1 else res
+            return fan_out
+        if name in SHARED_PARAMS:
+            return self._get_single(name)
+        res = [getattr(d, name) for d in self.datasets]
+        return res[0] if len(res) == 1 else res
+
+    def __getitem__(self, idx):
+        if isinstance(idx, (int, slice)):
+            return self.datasets[idx]
+        if idx in SHARED_PARAMS:
+            return self._get_single(idx)
+        res = [d[idx] for d in self.datasets]
+        return res[0] if len(res) == 1 else res
+
+    def __setitem__(self, key, value):
+        for d in self.datasets:
+            d[key] = value
+
+    def __len__(self):
+        return len(self.datasets)
+
+    def append(self, dataset):
+        self.datasets.append(dataset)

@@ -1,0 +1,242 @@
+"""Host driver of the MI355X channel-generation kernels.
+
+``ChannelEngine`` owns nothing but a device index: it takes the float32 ray matrices a
+``Dataset`` holds (core.py:209-219 layout), keeps them as PyTorch-ROCm tensors (PyTorch is the
+allocator / stream provider, not the compute path), fills the C structs of
+include/deepmimo_amd.h and calls the C-ABI:
+
+    dmx_path_prep   -> per-path records + side products (LoS, path counts, FoV mask, angles, powers)
+    dmx_channels_fd -> complex64 [N, M_rx, M_tx, K]     (dmx_channels_fd_lpf when rx_filter = 1)
+    dmx_channels_td -> complex64 [N, M_rx, M_tx, P]
+
+It replaces the body of Dataset.compute_channels (deepmimo/generator/dataset.py:224-268).
+No CPU path exists here: without the shared library or without a GPU every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from . import consts as c
+
+
+def _require_gpu(device_index: int) -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("deepmimo_amd: no GPU visible (torch.cuda.is_available() is False); the channel-"
+                           "generation path has no CPU fallback.")
+    return torch.device("cuda", int(device_index))
+
+
+@dataclass
+class DeviceRays:
+    """Ray matrices resident in HBM (float32 [N, L] each, contiguous)."""
+    n_ue: int
+    n_paths: int
+    fields: Dict[str, torch.Tensor]
+    doppler_vel: Optional[torch.Tensor] = None
+    doppler_acc: Optional[torch.Tensor] = None
+
+
+@dataclass
+class PrepResult:
+    workspace: torch.Tensor
+    n_ue: int
+    n_paths_loaded: int
+    params_struct: nat.DmxParams
+    keepalive: list = field(default_factory=list)
+    side: Dict[str, torch.Tensor] = field(default_factory=dict)
+
+
+def is_full_fov(fov) -> bool:
+    """dataset.py:450-459"""
+    return fov[0] >= 360 and fov[1] >= 180
+
+
+class ChannelEngine:
+    def __init__(self, device_index: int = 0):
+        self.lib = nat.load()
+        self.device = _require_gpu(device_index)
+
+    # ------------------------------------------------------------------ uploads
+    def upload_rays(self, data) -> DeviceRays:
+        """data: mapping with the eight float32 [N, L] matrices (numpy or torch)."""
+        fields = {}
+        shape = None
+        for k in c.RAY_FIELDS:
+            v = data[k]
+            t = v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+            t = t.to(device=self.device, dtype=torch.float32).contiguous()
+            if t.dim() != 2:
+                raise ValueError(f"ray matrix '{k}' must be 2-D [n_ue, n_paths], got {tuple(t.shape)}")
+            if shape is None:
+                shape = tuple(t.shape)
+            elif tuple(t.shape) != shape:
+                raise ValueError(f"ray matrix '{k}' has shape {tuple(t.shape)}, expected {shape}")
+            fields[k] = t
+        dv = da = None
+        keys = data.keys() if hasattr(data, "keys") else ()
+        if c.DOPPLER_VEL_PARAM_NAME in keys and c.DOPPLER_ACC_PARAM_NAME in keys:
+            dv = self._to_dev_f32(data[c.DOPPLER_VEL_PARAM_NAME])
+            da = self._to_dev_f32(data[c.DOPPLER_ACC_PARAM_NAME])
+        return DeviceRays(n_ue=shape[0], n_paths=shape[1], fields=fields, doppler_vel=dv, doppler_acc=da)
+
+    def _to_dev_f32(self, v):
+        t = v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+        return t.to(device=self.device, dtype=torch.float32).contiguous()
+
+    # ------------------------------------------------------------------ C structs
+    def _params_struct(self, params, bs_fov, ue_fov, ue_rot_per_user: Optional[torch.Tensor],
+                       sel_dev: Optional[torch.Tensor], carrier_freq: float, have_doppler: bool) -> nat.DmxParams:
+        bs, ue, ofdm = params[c.PARAMSET_ANT_BS], params[c.PARAMSET_ANT_UE], params[c.PARAMSET_OFDM]
+        p = nat.DmxParams()
+        p.bs_shape[0], p.bs_shape[1] = int(bs[c.PARAMSET_ANT_SHAPE][0]), int(bs[c.PARAMSET_ANT_SHAPE][1])
+        p.ue_shape[0], p.ue_shape[1] = int(ue[c.PARAMSET_ANT_SHAPE][0]), int(ue[c.PARAMSET_ANT_SHAPE][1])
+        p.bs_spacing, p.ue_spacing = float(bs[c.PARAMSET_ANT_SPACING]), float(ue[c.PARAMSET_ANT_SPACING])
+        bs_rot = np.deg2rad(np.asarray(bs[c.PARAMSET_ANT_ROTATION]))          # geometry.py:286
+        for i in range(3):
+            p.bs_rotation[i] = float(bs_rot[i])
+        if ue_rot_per_user is None:
+            ue_rot = np.deg2rad(np.asarray(ue[c.PARAMSET_ANT_ROTATION]))
+            for i in range(3):
+                p.ue_rotation[i] = float(ue_rot[i])
+            p.ue_rotation_per_user = None
+        else:
+            p.ue_rotation_per_user = ue_rot_per_user.data_ptr()
+        for side, key in ((bs, "bs_pattern"), (ue, "ue_pattern")):
+            name = side[c.PARAMSET_ANT_RAD_PAT]
+            if name not in c.PARAMSET_ANT_RAD_PAT_VALS:                      # ant_patterns.py:119-120
+                raise NotImplementedError(f"The given '{name}' antenna radiation pattern is not applicable.")
+            setattr(p, key, nat.PATTERN_IDS[name])
+        # FoV (dataset.py:477-504); apply_fov always stores both, a lone None is the full sphere
+        if bs_fov is not None and ue_fov is None:
+            ue_fov = np.array([360, 180])
+        if ue_fov is not None and bs_fov is None:
+            bs_fov = np.array([360, 180])
+        bs_full = bs_fov is not None and is_full_fov(bs_fov)
+        ue_full = ue_fov is not None and is_full_fov(ue_fov)
+        enabled = not ((bs_fov is None and ue_fov is None) or (bs_full and ue_full))
+        p.fov_enabled = int(enabled)
+        if enabled:
+            p.bs_fov_restricted, p.ue_fov_restricted = int(not bs_full), int(not ue_full)
+            b, u = np.deg2rad(np.asarray(bs_fov)), np.deg2rad(np.asarray(ue_fov))   # geometry.py:184
+            p.bs_fov[0], p.bs_fov[1], p.ue_fov[0], p.ue_fov[1] = float(b[0]), float(b[1]), float(u[0]), float(u[1])
+        p.num_paths = int(params[c.PARAMSET_NUM_PATHS])
+        p.freq_domain = int(bool(params[c.PARAMSET_FD_CH]))
+        p.n_subcarriers = int(ofdm[c.PARAMSET_OFDM_SC_NUM])
+        p.n_selected = 0 if sel_dev is None else int(sel_dev.numel())
+        p.selected_subcarriers = None if sel_dev is None or sel_dev.numel() == 0 else sel_dev.data_ptr()
+        p.bandwidth = float(ofdm[c.PARAMSET_OFDM_BANDWIDTH])
+        p.rx_filter = int(bool(ofdm[c.PARAMSET_OFDM_LPF]))
+        p.enable_doppler = int(bool(params[c.PARAMSET_DOPPLER_EN]) and have_doppler)
+        p.carrier_freq = float(carrier_freq)
+        return p
+
+    def _stream_ptr(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ stage 1
+    def prepare(self, rays: DeviceRays, params, bs_fov=None, ue_fov=None, ue_rotation_per_user=None,
+                carrier_freq: float = 0.0, want_side: bool = True) -> PrepResult:
+        """Run dmx_path_prep.  ue_rotation_per_user: optional [N, 3] degrees (numpy/torch)."""
+        dev = self.device
+        n, L = rays.n_ue, rays.n_paths
+        ofdm = params[c.PARAMSET_OFDM]
+        keep = []
+        sel = np.asarray(ofdm[c.PARAMSET_OFDM_SC_SAMP]).astype(np.int64).ravel()
+        sel_dev = torch.from_numpy(sel.astype(np.int32)).to(dev)
+        keep.append(sel_dev)
+        rot_dev = None
+        if ue_rotation_per_user is not None:
+            r = ue_rotation_per_user
+            r = r if isinstance(r, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(r, dtype=np.float64))
+            rot_dev = r.to(device=dev, dtype=torch.float64).contiguous()
+            if tuple(rot_dev.shape) != (n, 3):
+                raise ValueError(f"per-user UE rotation must be [n_ue, 3], got {tuple(rot_dev.shape)}")
+            keep.append(rot_dev)
+        have_dop = rays.doppler_vel is not None and rays.doppler_acc is not None
+        p = self._params_struct(params, bs_fov, ue_fov, rot_dev, sel_dev, carrier_freq, have_dop)
+
+        r = nat.DmxRays()
+        r.n_ue, r.n_paths, r.ld = n, L, L
+        for k in c.RAY_FIELDS:
+            setattr(r, k, rays.fields[k].data_ptr() if n * L > 0 else None)
+        r.doppler_vel = rays.doppler_vel.data_ptr() if have_dop and n * L > 0 else None
+        r.doppler_acc = rays.doppler_acc.data_ptr() if have_dop and n * L > 0 else None
+
+        nbytes = int(self.lib.dmx_workspace_bytes(C.byref(p), n, L))
+        ws = torch.empty(max(nbytes, 256) + 256, dtype=torch.uint8, device=dev)
+        off = (-ws.data_ptr()) % 256
+        ws = ws[off:off + max(nbytes, 256)]
+
+        side = {}
+        s = nat.DmxSide()
+        if want_side:
+            side["fov_mask"] = torch.empty((n, L), dtype=torch.uint8, device=dev) if p.fov_enabled else None
+            side["num_paths"] = torch.empty((n,), dtype=torch.int32, device=dev)
+            side["los"] = torch.empty((n,), dtype=torch.int32, device=dev)
+            for k in ("aod_el_rot", "aod_az_rot", "aoa_el_rot", "aoa_az_rot", "power_linear_ant_gain"):
+                side[k] = torch.empty((n, L), dtype=torch.float64, device=dev)
+            side["power_linear"] = torch.empty((n, L), dtype=torch.float32, device=dev)
+        side["max_delay_key"] = torch.zeros((1,), dtype=torch.int32, device=dev)
+        for k, t in side.items():
+            if t is not None and t.numel() > 0:
+                setattr(s, k, t.data_ptr())
+        with torch.cuda.device(dev):
+            rc = self.lib.dmx_path_prep(C.byref(r), C.byref(p), C.c_void_p(ws.data_ptr()), nbytes, C.byref(s),
+                                        self._stream_ptr())
+        nat.check(rc, "dmx_path_prep")
+        keep.extend(rays.fields.values())
+        return PrepResult(workspace=ws, n_ue=n, n_paths_loaded=L, params_struct=p, keepalive=keep, side=side)
+
+    # ------------------------------------------------------------------ stage 2
+    def channel_shape(self, prep: PrepResult, user_count: Optional[int] = None):
+        p = prep.params_struct
+        n = prep.n_ue if user_count is None else user_count
+        m_rx, m_tx = p.ue_shape[0] * p.ue_shape[1], p.bs_shape[0] * p.bs_shape[1]
+        last = p.n_selected if p.freq_domain else min(p.num_paths, prep.n_paths_loaded)
+        return (n, m_rx, m_tx, last)
+
+    def channels(self, prep: PrepResult, out: Optional[torch.Tensor] = None, user_begin: int = 0,
+                 user_count: Optional[int] = None, variant: int = 0) -> torch.Tensor:
+        """Run stage 2 for users [user_begin, user_begin + user_count) into `out` (allocated if None)."""
+        p = prep.params_struct
+        if user_count is None:
+            user_count = prep.n_ue - user_begin
+        shape = self.channel_shape(prep, user_count)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.complex64, device=self.device)
+        else:
+            if out.dtype != torch.complex64 or tuple(out.shape) != shape or not out.is_contiguous():
+                raise ValueError(f"out must be a contiguous complex64 tensor of shape {shape}")
+        if out.numel() == 0:
+            return out
+        wsp = C.c_void_p(prep.workspace.data_ptr())
+        with torch.cuda.device(self.device):
+            if p.freq_domain and p.rx_filter:
+                nbytes = int(self.lib.dmx_lpf_workspace_bytes(C.byref(p), user_count, prep.n_paths_loaded))
+                lws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+                off = (-lws.data_ptr()) % 256
+                rc = self.lib.dmx_channels_fd_lpf(C.byref(p), wsp, prep.n_ue, prep.n_paths_loaded, user_begin,
+                                                  user_count, C.c_void_p(lws.data_ptr() + off), nbytes,
+                                                  C.c_void_p(out.data_ptr()), self._stream_ptr())
+                nat.check(rc, "dmx_channels_fd_lpf")
+                prep.keepalive.append(lws)
+            elif p.freq_domain:
+                rc = self.lib.dmx_channels_fd(C.byref(p), wsp, prep.n_ue, prep.n_paths_loaded, user_begin, user_count,
+                                              C.c_void_p(out.data_ptr()), int(variant), self._stream_ptr())
+                nat.check(rc, "dmx_channels_fd")
+            else:
+                rc = self.lib.dmx_channels_td(C.byref(p), wsp, prep.n_ue, prep.n_paths_loaded, user_begin, user_count,
+                                              C.c_void_p(out.data_ptr()), self._stream_ptr())
+                nat.check(rc, "dmx_channels_td")
+        return out
+
+    def max_delay(self, prep: PrepResult) -> float:
+        """nanmax(delay[:, :P]) as the kernel saw it (channel.py:231); synchronises."""
+        key = int(prep.side["max_delay_key"].cpu().numpy().astype(np.uint32)[0])
+        return float(self.lib.dmx_decode_max_delay(key))

@@ -1,0 +1,155 @@
+/*
+ * deepmimo_amd.h - C-ABI of the MI355X-native DeepMIMO channel-generation path.
+ *
+ * The reference (jmoraispk/DeepMIMO v4.0.0a3) is pure Python and has no FFI: the seam this
+ * library sits behind is the method  Dataset.compute_channels(params)
+ * (deepmimo/generator/dataset.py:224-268) and the lazy attributes it feeds (`channel`, `los`,
+ * `num_paths`, `_fov_mask`, rotated angles, powers; dataset.py:831-869).  A maintainer binds
+ * these entry points with ctypes (INTEGRATION.md shows the stub).  Everything is plain C:
+ * borrowed DEVICE pointers + sizes in, caller-allocated DEVICE buffers out, a hipStream_t passed
+ * as void*.  The library allocates nothing, keeps no global state except a thread-local error
+ * string, launches asynchronously on the given stream and never synchronises.
+ *
+ * Layouts: ray fields are float32 row-major [n_ue, ld] (ld >= n_paths), NaN = "no path", exactly
+ * the arrays Dataset holds after core.py:209-219.  The channel tensor is complex64 interleaved
+ * (re, im), C-contiguous [n_ue, M_rx, M_tx, K] (frequency domain) or [n_ue, M_rx, M_tx, P]
+ * (time domain), last index fastest, as channel.py:257 allocates it.
+ */
+#ifndef DEEPMIMO_AMD_H
+#define DEEPMIMO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMX_ABI_VERSION 1
+
+/* status codes (0 = ok).  dmx_last_error() holds the message of the last failure on this thread. */
+#define DMX_OK               0
+#define DMX_ERR_ARG         -1   /* NULL / inconsistent argument */
+#define DMX_ERR_SHAPE       -2   /* shape outside what the kernels support */
+#define DMX_ERR_LAUNCH      -3   /* hipLaunch / runtime failure */
+#define DMX_ERR_WORKSPACE   -4   /* workspace too small or misaligned */
+
+/* radiation patterns: deepmimo/consts.py:254, deepmimo/generator/ant_patterns.py:21-71 */
+#define DMX_PATTERN_ISOTROPIC        0
+#define DMX_PATTERN_HALFWAVE_DIPOLE  1
+
+/* Ray-path records of one (TX, RX-set) pair: the float32 matrices of core.py:209-219. */
+typedef struct dmx_rays {
+    int64_t n_ue;          /* users (rows) */
+    int32_t n_paths;       /* loaded paths per user (columns) */
+    int32_t ld;            /* row stride in elements, >= n_paths */
+    const float* power;    /* dBW                        consts.py:188 */
+    const float* phase;    /* degrees                    consts.py:189 */
+    const float* delay;    /* seconds                    consts.py:190 */
+    const float* aoa_az;   /* degrees                    consts.py:191 */
+    const float* aoa_el;   /* degrees, zenith            consts.py:192 */
+    const float* aod_az;   /* degrees                    consts.py:193 */
+    const float* aod_el;   /* degrees, zenith            consts.py:194 */
+    const float* inter;    /* interaction code, 0 = LoS  consts.py:197 */
+    const float* doppler_vel;  /* m/s, optional (NULL)   deepmimo_v3/consts.py:63 */
+    const float* doppler_acc;  /* m/s^2, optional (NULL) deepmimo_v3/consts.py:64 */
+} dmx_rays;
+
+/* Channel parameters: ChannelGenParameters (channel.py:33-63) after validate() (:78-139), plus
+ * the FoV pair Dataset.apply_fov stored (dataset.py:423-448).  Angles in RADIANS as the host's
+ * np.deg2rad produced them (float64), so the device sees the reference's exact doubles. */
+typedef struct dmx_params {
+    int32_t bs_shape[2];          /* [Mh, Mv]; element m = y + Mh*z   geometry.py:105-120 */
+    int32_t ue_shape[2];
+    double  bs_spacing;           /* wavelengths */
+    double  ue_spacing;
+    double  bs_rotation[3];       /* radians about x, y, z            geometry.py:286-291 */
+    double  ue_rotation[3];       /* radians; used when ue_rotation_per_user == NULL */
+    const double* ue_rotation_per_user; /* device [n_ue, 3] DEGREES (dataset.py:329-338) or NULL */
+    int32_t bs_pattern;           /* DMX_PATTERN_* */
+    int32_t ue_pattern;
+    int32_t fov_enabled;          /* 0: Dataset._compute_fov returns mask None (dataset.py:484) */
+    int32_t bs_fov_restricted;    /* dataset.py:497 */
+    int32_t ue_fov_restricted;    /* dataset.py:502 */
+    double  bs_fov[2];            /* radians [horizontal, vertical]   geometry.py:184 */
+    double  ue_fov[2];
+    int32_t num_paths;            /* params.num_paths; min(num_paths, rays.n_paths) paths are used */
+    int32_t freq_domain;          /* 1: OFDM channel, 0: time-domain taps   channel.py:54 */
+    int32_t n_subcarriers;        /* ofdm.subcarriers (N) */
+    int32_t n_selected;           /* K = len(ofdm.selected_subcarriers) */
+    const int32_t* selected_subcarriers; /* device [K] */
+    double  bandwidth;            /* Hz; Ts = 1/bandwidth             channel.py:223 */
+    int32_t rx_filter;            /* ofdm.rx_filter (LPF / sinc interpolation)  channel.py:193-194 */
+    int32_t enable_doppler;       /* apply the v3 Doppler term (construct_deepmimo.py:267-280) */
+    double  carrier_freq;         /* Hz, for Doppler */
+} dmx_params;
+
+/* Optional side products of the path-prep stage (any pointer may be NULL = not wanted).
+ * All device pointers; [n_ue, n_paths] arrays are dense row-major with row stride n_paths. */
+typedef struct dmx_side {
+    uint8_t*  fov_mask;              /* [n_ue, n_paths] 0/1                 dataset.py:494-504 */
+    int32_t*  num_paths;             /* [n_ue]                              dataset.py:613-619 */
+    int32_t*  los;                   /* [n_ue] in {-1, 0, 1}                dataset.py:569-611 */
+    double*   aod_el_rot;            /* [n_ue, n_paths] radians, before FoV masking  dataset.py:341-349 */
+    double*   aod_az_rot;
+    double*   aoa_el_rot;
+    double*   aoa_az_rot;
+    float*    power_linear;          /* [n_ue, n_paths] W                   dataset.py:694-696 */
+    double*   power_linear_ant_gain; /* [n_ue, n_paths] W                   dataset.py:665-691 */
+    uint32_t* max_delay_key;         /* [1], caller zeroes it; order-preserving key of
+                                        nanmax(delay[:, :P]) (channel.py:231), see dmx_decode_max_delay */
+} dmx_side;
+
+/* ABI version of the loaded library (== DMX_ABI_VERSION of the header it was built from). */
+int dmx_version(void);
+
+/* Message of the last failing call on the calling thread ("" if none). */
+const char* dmx_last_error(void);
+
+/* Bytes of device workspace dmx_path_prep needs for n_ue users (256-byte aligned base required). */
+size_t dmx_workspace_bytes(const dmx_params* prm, int64_t n_ue, int32_t n_paths_loaded);
+
+/* Decode *max_delay_key (copied back to the host) into seconds; NaN when no finite delay was seen. */
+float dmx_decode_max_delay(uint32_t key);
+
+/*
+ * Stage 1 (replaces dataset.py:310-356 rotate, :461-512 FoV, :665-696 powers/patterns, :569-619
+ * LoS/path counts, and the per-path part of channel.py:170-198): one pass over the ray matrices
+ * that fills the compact per-path records in `workspace` and the requested side products.
+ */
+int dmx_path_prep(const dmx_rays* rays, const dmx_params* prm, void* workspace, size_t workspace_bytes,
+                  const dmx_side* side, void* stream);
+
+/*
+ * Stage 2, frequency domain (replaces dataset.py:398-417 array-response product and the user loop
+ * channel.py:264-284): out[u, rx, tx, k] = sum_l a_rx[rx,l] a_tx[tx,l] c_l exp(-j 2pi dn_l sc_k / N)
+ * for users [user_begin, user_begin + user_count) of the prepared workspace; `out` points at the
+ * first of those users (complex64 [user_count, M_rx, M_tx, K]).
+ * variant: 0 = automatic; 1 = fp32 vector kernel; 2 = split-precision MFMA kernel.
+ */
+int dmx_channels_fd(const dmx_params* prm, const void* workspace, int64_t n_ue, int32_t n_paths_loaded,
+                    int64_t user_begin, int64_t user_count, void* out_c64, int32_t variant, void* stream);
+
+/*
+ * Stage 2, frequency domain with the receive low-pass filter (ofdm.rx_filter = 1; replaces
+ * channel.py:166-168, 193-194): g[l,k] = sum_d c_l sinc(d - dn_l) exp(-j 2pi d sc_k / N) is first
+ * written to `lpf_workspace` (dmx_lpf_workspace_bytes(prm, user_count, n_paths_loaded) bytes,
+ * 256-byte aligned, device), then contracted as in dmx_channels_fd.
+ */
+size_t dmx_lpf_workspace_bytes(const dmx_params* prm, int64_t user_count, int32_t n_paths_loaded);
+int dmx_channels_fd_lpf(const dmx_params* prm, const void* workspace, int64_t n_ue, int32_t n_paths_loaded,
+                        int64_t user_begin, int64_t user_count, void* lpf_workspace, size_t lpf_workspace_bytes,
+                        void* out_c64, void* stream);
+
+/*
+ * Stage 2, time domain (replaces channel.py:285-287): out[u, rx, tx, s] = a_rx a_tx sqrt(p) e^{j phase}
+ * of the s-th valid path (valid paths compacted to the front, remaining slots zero),
+ * complex64 [user_count, M_rx, M_tx, P], P = min(num_paths, n_paths_loaded).
+ */
+int dmx_channels_td(const dmx_params* prm, const void* workspace, int64_t n_ue, int32_t n_paths_loaded,
+                    int64_t user_begin, int64_t user_count, void* out_c64, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPMIMO_AMD_H */

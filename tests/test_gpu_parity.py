@@ -1,0 +1,244 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the public
+Dataset API and therefore through the C-ABI, against (a) the golden vectors the real reference
+produced and (b) the NumPy oracle on seeded synthetic rays.
+
+Tolerance (BASELINE.json north_star / SURVEY.md 8c): |dH| <= 5e-5 * max|H_ref[user]| + 1e-12;
+LoS, path counts and FoV masks bit-exact; power_linear rtol 1e-6."""
+import numpy as np
+import pytest
+
+from tests._cases import (golden_names, load_golden, oracle_params, fov_args, assert_channel_close, TOL_REL)
+
+pytestmark = pytest.mark.gpu
+
+
+def _dm_params(case, ue_rot):
+    import deepmimo_amd as dm
+    p = dm.ChannelGenParameters()
+    p.bs_antenna.shape = np.array(case["bs_shape"])
+    p.ue_antenna.shape = np.array(case["ue_shape"])
+    p.bs_antenna.spacing = case["bs_spacing"]
+    p.ue_antenna.spacing = case["ue_spacing"]
+    p.bs_antenna.rotation = np.array(case["bs_rot"])
+    p.ue_antenna.rotation = np.array(ue_rot)
+    p.bs_antenna.radiation_pattern = case["bs_pattern"]
+    p.ue_antenna.radiation_pattern = case["ue_pattern"]
+    p.num_paths = case["num_paths"]
+    p.freq_domain = case["freq_domain"]
+    p.ofdm.subcarriers = case["subcarriers"]
+    p.ofdm.selected_subcarriers = np.array(case["selected"])
+    p.ofdm.bandwidth = case["bandwidth"]
+    p.ofdm.rx_filter = case["rx_filter"]
+    return p
+
+
+def _dataset(case, rays, with_doppler=False):
+    import deepmimo_amd as dm
+    d = {k: v.copy() for k, v in rays.items() if with_doppler or not k.startswith("doppler")}
+    ds = dm.Dataset(d)
+    bs_fov, ue_fov = fov_args(case)
+    if bs_fov is not None or ue_fov is not None:
+        kw = {}
+        if bs_fov is not None:
+            kw["bs_fov"] = bs_fov
+        if ue_fov is not None:
+            kw["ue_fov"] = ue_fov
+        ds.apply_fov(**kw)
+    return ds
+
+
+@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("name", golden_names())
+def test_golden(name, variant, capsys):
+    import deepmimo_amd as dm
+    case, rays, ue_rot, ref = load_golden(name)
+    dm.config("fd_kernel_variant", variant)
+    try:
+        ds = _dataset(case, rays)
+        H = ds.compute_channels(_dm_params(case, ue_rot))
+    finally:
+        dm.config("fd_kernel_variant", 0)
+    assert H.dtype == np.complex64
+    if "channel" in ref:
+        assert_channel_close(H, ref["channel"], what=name)
+    else:
+        sub = case["subsample"]
+        assert_channel_close(H[:, :, sub["tx"], :][..., sub["k"]], ref["channel_sub"], what=name)
+        # size-independent fingerprint of the full tensor
+        Hd = H.astype(np.complex128)
+        e = float(np.sum(np.abs(Hd) ** 2))
+        assert abs(e - ref["channel_checksum"][0]) <= 4 * TOL_REL * ref["channel_checksum"][0]
+    np.testing.assert_array_equal(ds.los, ref["los"])
+    np.testing.assert_array_equal(ds.num_paths, ref["num_paths"])
+    assert ds.los.dtype == ref["los"].dtype and ds.num_paths.dtype == ref["num_paths"].dtype
+    if "fov_mask" in ref:
+        np.testing.assert_array_equal(ds["_fov_mask"], ref["fov_mask"])
+    else:
+        assert ds["_fov_mask"] is None
+    np.testing.assert_allclose(ds.power_linear, ref["power_linear"], rtol=1e-6, equal_nan=True)
+    assert ds.power_linear.dtype == ref["power_linear"].dtype
+    g = ds["_power_linear_ant_gain"]
+    assert g.dtype == ref["power_linear_ant_gain"].dtype
+    np.testing.assert_allclose(g, ref["power_linear_ant_gain"], rtol=2e-6, atol=1e-30, equal_nan=True)
+    for k in ("aod_el_rot", "aod_az_rot", "aoa_el_rot", "aoa_az_rot"):
+        np.testing.assert_allclose(ds["_" + k], ref[k], rtol=0, atol=2e-6, equal_nan=True)
+    if case["freq_domain"]:
+        warned = "exceed OFDM symbol duration" in capsys.readouterr().out
+        assert warned == bool(ref["warned"])
+
+
+def test_doppler_golden():
+    """Doppler term: golden from the v3 generator (the only Python definition, SURVEY finding 4)."""
+    import deepmimo_amd as dm
+    case, rays, ue_rot, ref = load_golden("g10_doppler_v3")
+    ds = _dataset(case, rays, with_doppler=True)
+    ds["rt_params"] = {"frequency": 3.5e9}
+    p = _dm_params(case, ue_rot)
+    p.enable_doppler = 1
+    H = ds.compute_channels(p)
+    assert_channel_close(H, ref["channel_doppler"], what="doppler")
+    p.enable_doppler = 0
+    assert_channel_close(ds.compute_channels(p), ref["channel"], what="doppler off")
+
+
+SHAPES = [
+    # n_ue, L, bs, ue, N, selected, extra
+    (37, 1, [1, 1], [1, 1], 16, list(range(16)), {}),
+    (50, 3, [3, 1], [1, 3], 100, [0, 99, 50, 7, 7], {}),                      # unsorted / repeated subcarriers
+    (33, 7, [5, 3], [3, 1], 96, list(range(0, 96, 1)), dict(bs_rot=[0, 90, 0])),
+    (20, 16, [4, 4], [2, 2], 128, list(range(1, 128, 2)), dict(ue_rot=[45, -30, 170])),
+    (12, 25, [8, 8], [2, 2], 512, list(range(0, 512, 3)), dict(max_delay=40e-6)),
+    (9, 32, [16, 2], [1, 2], 64, list(range(64)), {}),
+    (6, 25, [16, 16], [4, 4], 1024, list(range(0, 1024, 16)), dict(all_valid=True, max_delay=90e-6)),
+    (5, 12, [70, 1], [1, 1], 64, list(range(64)), {}),
+]
+
+
+@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("shape", SHAPES, ids=[f"s{i}" for i in range(len(SHAPES))])
+def test_vs_oracle_shapes(shape, variant):
+    """Seeded synthetic rays at ragged shapes (K not a multiple of 64, odd panels, 1..32 paths)."""
+    import deepmimo_amd as dm
+    from oracle import oracle_np as onp
+    n, L, bs, ue, N, sel, extra = shape
+    rays = onp.synth_rays(n, L, seed=1000 + n, all_valid=extra.get("all_valid", False),
+                          max_delay=extra.get("max_delay", 2e-6))
+    case = dict(bs_shape=bs, ue_shape=ue, bs_spacing=0.5, ue_spacing=0.37, bs_rot=extra.get("bs_rot", [0, 0, 0]),
+                bs_pattern="isotropic", ue_pattern="isotropic", num_paths=L, freq_domain=1, subcarriers=N,
+                selected=sel, bandwidth=20e6, rx_filter=0, bs_fov=None, ue_fov=None)
+    ue_rot = np.array(extra.get("ue_rot", [0, 0, 0]))
+    ref = onp.compute_channels(rays, oracle_params(case, ue_rot))
+    dm.config("fd_kernel_variant", variant)
+    try:
+        ds = dm.Dataset(dict(rays))
+        H = ds.compute_channels(_dm_params(case, ue_rot))
+    finally:
+        dm.config("fd_kernel_variant", 0)
+    assert_channel_close(H, ref["channel"], what=str(shape[:5]))
+    np.testing.assert_array_equal(ds.los, ref["los"])
+    np.testing.assert_array_equal(ds.num_paths, ref["num_paths"])
+
+
+def test_time_domain_and_lpf_vs_oracle():
+    import deepmimo_amd as dm
+    from oracle import oracle_np as onp
+    rays = onp.synth_rays(40, 9, seed=77)
+    for fd, lpf in ((0, 0), (1, 1)):
+        case = dict(bs_shape=[4, 2], ue_shape=[2, 1], bs_spacing=0.5, ue_spacing=0.5, bs_rot=[20, 10, -60],
+                    bs_pattern="halfwave-dipole", ue_pattern="isotropic", num_paths=9, freq_domain=fd,
+                    subcarriers=48, selected=list(range(0, 48, 5)), bandwidth=15e6, rx_filter=lpf,
+                    bs_fov=[150, 100], ue_fov=None)
+        ue_rot = np.array([0, 15, 0])
+        ref = onp.compute_channels(rays, oracle_params(case, ue_rot), bs_fov=np.array([150, 100]),
+                                   ue_fov=np.array([360, 180]))
+        ds = _dataset(case, rays)
+        H = ds.compute_channels(_dm_params(case, ue_rot))
+        assert_channel_close(H, ref["channel"], what=f"fd={fd} lpf={lpf}")
+        np.testing.assert_array_equal(ds["_fov_mask"], ref["_fov_mask"])
+
+
+def test_empty_and_all_nan():
+    import deepmimo_amd as dm
+    from oracle import oracle_np as onp
+    rays = onp.synth_rays(0, 5, seed=1)
+    ds = dm.Dataset(dict(rays))
+    H = ds.compute_channels()
+    assert H.shape == (0, 1, 8, 1)
+    rays = onp.synth_rays(5, 4, seed=2)
+    for k in onp.RAY_KEYS:
+        rays[k][:] = np.nan
+    ds = dm.Dataset(dict(rays))
+    H = ds.compute_channels()
+    assert H.shape == (5, 1, 8, 1) and np.all(H == 0)
+    assert ds.los.tolist() == [-1] * 5 and ds.num_paths.tolist() == [0] * 5
+
+
+def test_cache_semantics_and_aliases():
+    """dataset.py:197-222, 358-378, 515-535: what is cached, what a rotation / FoV change drops."""
+    import deepmimo_amd as dm
+    from oracle import oracle_np as onp
+    rays = onp.synth_rays(16, 6, seed=3)
+    ds = dm.Dataset(dict(rays))
+    p = dm.ChannelGenParameters()
+    H1 = ds.compute_channels(p)
+    assert ds.channel is H1 and ds.ch is H1 and ds["channels"] is H1
+    assert "_aod_el_rot" in ds.keys() and "los" in ds.keys()
+    ds.apply_fov(bs_fov=np.array([90, 60]))
+    assert "channel" not in ds.keys() and "los" not in ds.keys() and "_aod_el_rot" in ds.keys()
+    n_before = ds.num_paths.copy()                  # lazy: triggers stage 1 with the new FoV
+    assert ds["_fov_mask"].dtype == bool
+    p.bs_antenna.rotation = np.array([0, 0, 90])
+    H2 = ds.compute_channels(p)
+    assert not np.array_equal(n_before, ds.num_paths) or not np.allclose(H1, H2)
+    # lazy channel with default params on a fresh dataset
+    ds2 = dm.Dataset(dict(rays))
+    assert ds2.channel.shape == (16, 1, 8, 1)
+    with pytest.raises(KeyError):
+        ds2["no_such_matrix"]
+
+
+def test_macro_dataset_fan_out():
+    import deepmimo_amd as dm
+    from oracle import oracle_np as onp
+    a, b = onp.synth_rays(8, 4, seed=5), onp.synth_rays(11, 4, seed=6)
+    md = dm.MacroDataset([dm.Dataset(dict(a)), dm.Dataset(dict(b))])
+    Hs = md.compute_channels()
+    assert isinstance(Hs, list) and Hs[0].shape[0] == 8 and Hs[1].shape[0] == 11
+    assert [x.shape[0] for x in md.los] == [8, 11]
+    single = dm.MacroDataset([dm.Dataset(dict(a))])
+    assert single.compute_channels().shape[0] == 8
+
+
+def test_random_ue_rotation_matches_reference_rng_order():
+    """(3, 2) UE rotation = random range, drawn after np.random.seed(1001) (dataset.py:250, 334-338)."""
+    case, rays, ue_rot, ref = load_golden("g09_random_ue_rot")
+    ds = _dataset(case, rays)
+    H = ds.compute_channels(_dm_params(case, ue_rot))
+    assert_channel_close(H, ref["channel"], what="random ue rot")
+    np.testing.assert_array_equal(ds["_fov_mask"], ref["fov_mask"])
+
+
+def test_errors_are_loud():
+    import deepmimo_amd as dm
+    from deepmimo_amd._native import NativeError
+    from oracle import oracle_np as onp
+    rays = onp.synth_rays(4, 3, seed=9)
+    ds = dm.Dataset(dict(rays))
+    p = dm.ChannelGenParameters()
+    p.bs_antenna.radiation_pattern = "patch"
+    with pytest.raises((AssertionError, NotImplementedError)):
+        ds.compute_channels(p)
+    p = dm.ChannelGenParameters()
+    p.bs_antenna.rotation = np.array([1, 2])
+    with pytest.raises(AssertionError):
+        ds.compute_channels(p)
+    p = dm.ChannelGenParameters()
+    p.ofdm.bandwidth = 0.0
+    with pytest.raises(NativeError):
+        ds.compute_channels(p)
+    dm.config("use_gpu", False)
+    try:
+        with pytest.raises(RuntimeError):
+            dm.Dataset(dict(rays)).compute_channels()
+    finally:
+        dm.config("use_gpu", True)

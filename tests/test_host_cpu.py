@@ -1,0 +1,174 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol the header
+declares (no compute without a GPU), parameter validation, DotDict, config, loader, aliases."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    from deepmimo_amd import _native
+    if not os.path.exists(_native.LIB_PATH):
+        g.build()
+    lib = _native.load()
+    header = open(os.path.join(ROOT, "include", "deepmimo_amd.h")).read()
+    declared = set(re.findall(r"\b(dmx_[a-z_0-9]+)\s*\(", header))
+    declared -= {"dmx_rays", "dmx_params", "dmx_side"}
+    assert declared == set(_native.EXPORTED_SYMBOLS), (declared, _native.EXPORTED_SYMBOLS)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert lib.dmx_version() == _native.ABI_VERSION
+    # host-only entry points are callable without a GPU
+    p = _native.DmxParams()
+    p.num_paths = 25
+    assert lib.dmx_workspace_bytes(p, 1000, 25) >= 1000 * 25 * (3 * 4 + 4 * 8)
+    assert lib.dmx_workspace_bytes(p, 0, 25) % 256 == 0
+    assert np.isnan(lib.dmx_decode_max_delay(0))
+
+
+def test_struct_sizes_match_header_layout():
+    """ctypes mirrors must have the C layout (natural alignment, 8-byte pointers)."""
+    from deepmimo_amd import _native as n
+    import ctypes as C
+    assert C.sizeof(n.DmxRays) == 8 + 4 + 4 + 10 * 8
+    assert C.sizeof(n.DmxSide) == 10 * 8
+    assert n.DmxParams.ue_rotation_per_user.offset % 8 == 0
+    assert n.DmxParams.selected_subcarriers.offset % 8 == 0
+    assert n.DmxParams.carrier_freq.offset % 8 == 0
+
+
+def test_no_gpu_is_a_loud_error():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import deepmimo_amd as dm
+    from oracle import oracle_np as onp
+    ds = dm.Dataset(dict(onp.synth_rays(4, 3, seed=1)))
+    with pytest.raises(RuntimeError, match="no GPU"):
+        ds.compute_channels()
+    with pytest.raises(RuntimeError):
+        _ = ds.los
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under deepmimo_amd/ may import or link it."""
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|oracle_np|oracle/_ref|liboracle", re.M)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "deepmimo_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not pat.search(src), (dirpath, f)
+
+
+def test_channel_params_defaults_and_validate(capsys):
+    import deepmimo_amd as dm
+    p = dm.ChannelGenParameters()
+    assert p.bs_antenna.shape.tolist() == [8, 1] and p.ue_antenna.shape.tolist() == [1, 1]
+    assert p.num_paths == 25 and p.freq_domain == 1 and p.ofdm.subcarriers == 512
+    assert p.ofdm.selected_subcarriers.tolist() == [0] and p.ofdm.bandwidth == 10e6 and p.ofdm.rx_filter == 0
+    assert p["ofdm"]["bandwidth"] == p.ofdm.bandwidth
+    p.validate(10)
+    assert capsys.readouterr().out == ""
+    p.bs_antenna.fov = np.array([360, 180])             # a key v4 does not read
+    p.validate(10)
+    assert "unnecessary" in capsys.readouterr().out
+    q = dm.ChannelGenParameters()
+    q.bs_antenna.rotation = np.array([[0, 1, 2]])
+    with pytest.raises(AssertionError, match="BS antenna rotation"):
+        q.validate(10)
+    q = dm.ChannelGenParameters()
+    q.ue_antenna.rotation = np.zeros((4, 3))
+    with pytest.raises(AssertionError, match="UE antenna rotation"):
+        q.validate(10)
+    q.validate(4)
+    q = dm.ChannelGenParameters()
+    q.ue_antenna.rotation = np.array([[0, 10], [0, 20], [0, 30]])
+    q.validate(99)
+    q = dm.ChannelGenParameters()
+    q.ue_antenna.radiation_pattern = "yagi"
+    with pytest.raises(AssertionError, match="radiation pattern"):
+        q.validate(1)
+    c = p.deepcopy()
+    c.bs_antenna.shape[0] = 99
+    assert p.bs_antenna.shape[0] == 8 and isinstance(c, dm.ChannelGenParameters)
+
+
+def test_dotdict_and_config():
+    import deepmimo_amd as dm
+    d = dm.DotDict({"a": 1, "b": {"c": 2}})
+    assert d.a == 1 and d.b.c == 2 and d["b"]["c"] == 2 and list(d.keys()) == ["a", "b"]
+    d.x = {"y": 3}
+    assert isinstance(d.x, dm.DotDict) and d.to_dict()["x"] == {"y": 3}
+    with pytest.raises(AttributeError):
+        d.missing
+    assert d.get("missing", 5) == 5
+    dm.config("gpu_device_id", 3)
+    assert dm.config("gpu_device_id") == 3 and dm.config.get("use_gpu") is True
+    dm.config(gpu_device_id=0)
+    assert dm.config.get_all()["gpu_device_id"] == 0
+    dm.config.reset()
+    with pytest.raises(ValueError):
+        dm.config("a", 1, 2)
+
+
+def test_steering_vec_matches_oracle():
+    import deepmimo_amd as dm
+    from oracle import oracle_np as onp
+    for shape, phi, theta in (([8, 1], 0, 0), ([4, 2], 25, -10), ([3, 5], -70, 33)):
+        a = dm.steering_vec(np.array(shape), phi=phi, theta=theta, spacing=0.5)
+        b = onp.steering_vec(shape, phi=phi, theta=theta, spacing=0.5)
+        assert a.shape == (shape[0] * shape[1], 1)
+        np.testing.assert_allclose(a, b, atol=1e-14)
+        assert abs(np.linalg.norm(a) - 1) < 1e-12
+
+
+def test_dataset_host_logic_without_gpu():
+    import deepmimo_amd as dm
+    from oracle import oracle_np as onp
+    rays = onp.synth_rays(6, 4, seed=4)
+    ds = dm.Dataset(dict(rays))
+    assert ds.n_ue == 6 and ds.pwr is ds.power and ds["toa"] is ds.delay and ds.rx_loc is ds.rx_pos
+    assert ds.distance.shape == (6,) and ds.inter_int.dtype.kind == "i"
+    ds.apply_fov(bs_fov=np.array([100, 90]))
+    assert ds.bs_fov.tolist() == [100, 90] and ds.ue_fov.tolist() == [360, 180]
+    ds["channel"] = "sentinel"
+    ds["_aod_el_rot"] = "rot"
+    ds.apply_fov()
+    assert "channel" not in ds.keys() and ds["_aod_el_rot"] == "rot"
+    ds._clear_cache_rotated_angles()
+    assert "_aod_el_rot" not in ds.keys()
+    with pytest.raises(KeyError):
+        ds["nope"]
+    p = ds.ch_params                        # lazily resolves to defaults (dataset.py:839)
+    assert isinstance(p, dm.ChannelGenParameters)
+    np.testing.assert_allclose(ds.tx_ori, [0, 0, 0])
+
+
+def test_loader_reads_reference_layout(tmp_path):
+    """core.py:186-258 on-disk format: params.json + {key}_t000_tx000_r001.mat files."""
+    import json
+    import scipy.io
+    import deepmimo_amd as dm
+    from oracle import oracle_np as onp
+    rays = onp.synth_rays(12, 7, seed=8)
+    folder = tmp_path / "toy_scen"
+    folder.mkdir()
+    params = {"version": "4.0.0a3", "rt_params": {"frequency": 3.5e9},
+              "scene": {"num_scenes": 1}, "materials": {},
+              "txrx_sets": {"txrx_set_0": {"id": 0, "is_tx": True, "is_rx": False, "num_points": 1, "name": "bs"},
+                            "txrx_set_1": {"id": 1, "is_tx": False, "is_rx": True, "num_points": 12, "name": "ue"}}}
+    (folder / "params.json").write_text(json.dumps(params))
+    for k, v in rays.items():
+        scipy.io.savemat(str(folder / dm.core.get_mat_filename(k, 0, 0, 1)), {k: v})
+    ds = dm.load(str(folder), max_paths=5, rx_sets={1: [0, 2, 4, 6]})
+    assert isinstance(ds, dm.Dataset) and ds.power.shape == (4, 5) and ds.n_ue == 4
+    np.testing.assert_array_equal(ds.aoa_az, rays["aoa_az"][[0, 2, 4, 6], :5])
+    assert ds.rt_params["frequency"] == 3.5e9 and ds.txrx["rx_set_id"] == 1
+    with pytest.raises(ValueError):
+        dm.load(str(tmp_path / "missing"))
+    with pytest.raises(Exception):
+        dm.load(str(folder), tx_sets=[5])
