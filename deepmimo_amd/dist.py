@@ -1,0 +1,148 @@
+"""Multi-GPU layer of the channel path: users are independent (channel.py:264 iterates users with
+no cross-user state), so the path shards as contiguous user blocks, one process per GPU, with NO
+collective on the data path.  RCCL (torch.distributed backend "nccl" on ROCm) is used only to
+bring results together when the caller asks:
+
+  * ``all_gather_users``   - small per-user side products (``los``, ``num_paths``; int arrays)
+  * ``gather_users_to_root`` - a channel tensor (or a user / subcarrier slice of it) to one rank,
+    as a fan-in of point-to-point transfers straight into the destination rows.  xGMI is
+    point-to-point (7 links x ~153 GB/s per GPU): a root ingests on all its links at once, while a
+    ring gather would be bound by one link, so no ring collective is used here.
+
+The full tensors of the big configurations do not fit one GPU (1M users x 64x4 x 512 = 1.05 TB),
+so the default is sharded-resident output: each rank keeps its block (``ShardResult.channel``).
+Everything here also runs on the ``gloo`` backend with CPU tensors (that is how the CPU tests
+cover the N > 1 path); only ``compute_channels_sharded`` needs a GPU.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import consts as c
+
+
+def shard_bounds(n_ue: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous block partition: rank r owns users [r*ceil(N/G), min(N, (r+1)*ceil(N/G)))."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    per = -(-n_ue // world) if n_ue > 0 else 0
+    b = min(n_ue, rank * per)
+    return b, min(n_ue, b + per)
+
+
+def shard_sizes(n_ue: int, world: int) -> List[int]:
+    return [e - b for b, e in (shard_bounds(n_ue, world, r) for r in range(world))]
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def _world(group=None) -> Tuple[int, int]:
+    dist = _dist()
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def all_gather_users(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """Concatenate per-user shards (dim 0) from all ranks on every rank.  Shards follow
+    shard_bounds, so they may be ragged: they are padded to the largest shard for the collective."""
+    rank, world = _world(group)
+    sizes = shard_sizes(n_total, world)
+    if local.shape[0] != sizes[rank]:
+        raise ValueError(f"rank {rank}: local shard has {local.shape[0]} users, expected {sizes[rank]}")
+    if world == 1:
+        return local
+    dist = _dist()
+    per = max(sizes)
+    buf = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    buf[: local.shape[0]] = local
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf, group=group)
+    return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
+
+
+def gather_users_to_root(local: torch.Tensor, n_total: int, dst: int = 0, group=None,
+                         out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """Fan-in gather of per-user shards to rank `dst`: every peer sends its block once, the root
+    receives each block directly into its rows of the result (no staging copy, no ring)."""
+    rank, world = _world(group)
+    sizes = shard_sizes(n_total, world)
+    if local.shape[0] != sizes[rank]:
+        raise ValueError(f"rank {rank}: local shard has {local.shape[0]} users, expected {sizes[rank]}")
+    local = local.contiguous()
+    if world == 1:
+        if out is not None:
+            out.copy_(local)
+            return out
+        return local
+    dist = _dist()
+    if rank == dst:
+        if out is None:
+            out = torch.empty((n_total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        reqs = []
+        for r in range(world):
+            b, e = shard_bounds(n_total, world, r)
+            if e == b:
+                continue
+            if r == dst:
+                out[b:e].copy_(local)
+            else:
+                reqs.append(dist.irecv(out[b:e], src=r, group=group))
+        for q in reqs:
+            q.wait()
+        return out
+    if local.shape[0] > 0:
+        dist.send(local, dst=dst, group=group)
+    return None
+
+
+@dataclass
+class ShardResult:
+    channel: torch.Tensor            # complex64 [n_local, M_rx, M_tx, K or P], resident on this rank's GPU
+    user_begin: int
+    user_end: int
+    n_total: int
+    side: Dict[str, torch.Tensor]    # this rank's los / num_paths / ... (device tensors)
+
+
+def compute_channels_sharded(data, params, bs_fov=None, ue_fov=None, group=None, device_index: Optional[int] = None,
+                             want_side: bool = True, variant: int = 0) -> ShardResult:
+    """Each rank generates the channels of its own user block on its own GPU.
+
+    data: mapping with the full float32 [N, L] ray matrices (every rank may hold the full host
+    copy - 800 B per user - or a torch tensor); only the local rows are uploaded.  params:
+    ChannelGenParameters (validated by the caller).  A per-user UE rotation [N, 3] is sliced like
+    the rays; the random-range form (3, 2) must be resolved by the caller so that all ranks agree."""
+    from .engine import ChannelEngine
+    rank, world = _world(group)
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    n_total = int(data[c.POWER_PARAM_NAME].shape[0])
+    b, e = shard_bounds(n_total, world, rank)
+    eng = ChannelEngine(device_index)
+    local = {k: data[k][b:e] for k in c.RAY_FIELDS}
+    for k in (c.DOPPLER_VEL_PARAM_NAME, c.DOPPLER_ACC_PARAM_NAME):
+        if hasattr(data, "keys") and k in data.keys():
+            local[k] = data[k][b:e]
+    rays = eng.upload_rays(local)
+    rot = np.asarray(params[c.PARAMSET_ANT_UE][c.PARAMSET_ANT_ROTATION])
+    rot_pu = None
+    if rot.ndim == 2:
+        if rot.shape == (3, 2) and n_total != 3:
+            raise ValueError("resolve the random UE rotation range to [N, 3] before sharding")
+        rot_pu = rot[b:e]
+    carrier = 0.0
+    if hasattr(data, "keys") and c.RT_PARAMS_PARAM_NAME in data.keys():
+        carrier = float(data[c.RT_PARAMS_PARAM_NAME].get(c.RT_PARAM_FREQUENCY, 0.0))
+    prep = eng.prepare(rays, params, bs_fov=bs_fov, ue_fov=ue_fov, ue_rotation_per_user=rot_pu,
+                       carrier_freq=carrier, want_side=want_side)
+    chan = eng.channels(prep, variant=variant)
+    side = {k: v for k, v in prep.side.items() if v is not None and k != "max_delay_key"}
+    return ShardResult(channel=chan, user_begin=b, user_end=e, n_total=n_total, side=side)
