@@ -52,9 +52,13 @@ __host__ inline size_t ws_carve(void* base, int64_t n, int32_t P, WsView* v) {
     return off;
 }
 
-// sin/cos of 2*pi*r for r already reduced to about [-0.5, 0.5] revolutions.
+// sin/cos of 2*pi*r for r already reduced to [-0.5, 0.5] revolutions.  v_sin_f32 / v_cos_f32 take
+// their argument in revolutions, i.e. exactly this representation; measured max abs error on the
+// reduced range (tools/sincos_acc.hip, MI355X): 1.25e-7, against 5.2e-8 for sincospif at ~15x the
+// instructions.  All phase accuracy in this library lives in the float64 range reduction before.
 __device__ __forceinline__ void sincos_rev(float r, float& s, float& c) {
-    sincospif(2.0f * r, &s, &c);
+    s = __builtin_amdgcn_sinf(r);
+    c = __builtin_amdgcn_cosf(r);
 }
 
 // fractional part in [-0.5, 0.5] of a float64 phase given in revolutions

@@ -1,4 +1,5 @@
-// Stage 1 - path prep: one wavefront (64 lanes) per user, one lane per path.
+// Stage 1 - path prep: one lane per path; a wavefront serves two users (32 lanes each) when the
+// scenario has at most 32 loaded paths (DeepMIMO's MAX_PATHS is 25), one user otherwise.
 //
 // Replaces, for all users at once, the vectorised NumPy prologue of Dataset.compute_channels:
 //   _rotate_angles_batch        geometry.py:244-319   (via dataset.py:310-356)
@@ -54,8 +55,9 @@ __device__ __forceinline__ void rotate_one(float el_deg, float az_deg, double sx
                                            double cy, double rz, double& th, double& ph) {
     const float th32 = el_deg * D2R_F;
     const float ph32 = az_deg * D2R_F;
-    const double st = (double)(float)sin((double)th32);     // np.sin(float32) -> float32
-    const double ct = (double)(float)cos((double)th32);
+    float st32, ct32;
+    sincosf(th32, &st32, &ct32);                            // np.sin / np.cos of float32 stay float32
+    const double st = (double)st32, ct = (double)ct32;
     const double d = (double)ph32 - rz;
     double sd, cd;
     sincos(d, &sd, &cd);
@@ -88,15 +90,28 @@ __device__ __forceinline__ double dipole_gain(double th) {
     return 1.643 * (c * c / s);
 }
 
+// the bits of a 64-lane ballot that belong to group `grp` of LPU lanes, shifted down to bit 0
+template <int LPU>
+__device__ __forceinline__ unsigned long long group_mask(unsigned long long b, int grp) {
+    if constexpr (LPU == 64) return b;
+    else return (b >> (grp * LPU)) & ((1ull << LPU) - 1ull);
+}
+
 __device__ __forceinline__ uint32_t float_order_key(float f) {
     uint32_t b = __float_as_uint(f);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
+// LPU = lanes per user (32: two users share a wave; 64: one user per wave, any path count)
+template <int LPU>
 __global__ __launch_bounds__(256) void k1_path_prep(PrepArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (u >= a.rays.n_ue) return;                           // wave-uniform
+    constexpr int UPW = 64 / LPU;                           // users per wave
+    const int lane = threadIdx.x & (LPU - 1);               // lane inside the user's group
+    const int grp = (threadIdx.x & 63) / LPU;               // which group of the wave
+    const int64_t u_raw = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * UPW + grp;
+    const bool u_ok = u_raw < a.rays.n_ue;
+    if (__ballot(u_ok) == 0ull) return;                     // whole wave past the end
+    const int64_t u = u_ok ? u_raw : a.rays.n_ue - 1;       // idle group shadows the last user, writes nothing
     const dmx_rays& r = a.rays;
     const int L = r.n_paths;
     const size_t row = (size_t)u * (size_t)r.ld;
@@ -120,9 +135,9 @@ __global__ __launch_bounds__(256) void k1_path_prep(PrepArgs a) {
     float maxd = -INFINITY;
     bool any_delay = false;
 
-    for (int j0 = 0; j0 < L; j0 += 64) {
+    for (int j0 = 0; j0 < L; j0 += LPU) {
         const int j = j0 + lane;
-        const bool in = j < L;
+        const bool in = u_ok && j < L;
         const float power = in ? r.power[row + j] : nan32;
         const float phase = in ? r.phase[row + j] : nan32;
         const float delay = in ? r.delay[row + j] : nan32;
@@ -150,19 +165,20 @@ __global__ __launch_bounds__(256) void k1_path_prep(PrepArgs a) {
             mask = mask && in;
             if (in && a.side.fov_mask) a.side.fov_mask[srow + j] = mask ? 1 : 0;
             if (!mask) { th_t = nan64; ph_t = nan64; th_r = nan64; ph_r = nan64; }
-            const unsigned long long mb = __ballot(mask);
-            if (!has_fov_path && mb != 0ull) {               // first in-FoV path (dataset.py:594-598)
-                has_fov_path = true;
-                first_inter = __shfl(inter, __ffsll((long long)mb) - 1);
-            }
+            const unsigned long long mb = group_mask<LPU>(__ballot(mask), grp);
+            // first in-FoV path (dataset.py:594-598); the shuffle is executed by every lane, the
+            // result is kept only by groups that had no in-FoV path yet
+            const int src = mb != 0ull ? __ffsll((long long)mb) - 1 : 0;
+            const float cand = __shfl(inter, src, LPU);
+            if (!has_fov_path && mb != 0ull) { has_fov_path = true; first_inter = cand; }
         } else if (j0 == 0) {
-            first_inter = __shfl(inter, 0);                  // dataset.py:602
+            first_inter = __shfl(inter, 0, LPU);             // dataset.py:602
         }
-        count_paths += __popcll(__ballot(in && !isnan(ph_r)));   // dataset.py:616-619
+        count_paths += __popcll(group_mask<LPU>(__ballot(in && !isnan(ph_r)), grp));   // dataset.py:616-619
 
         // powers (generator_utils.py:35, ant_patterns.py:167-168)
         const float p10 = power / 10.0f;
-        const float pl = (float)pow(10.0, (double)p10);
+        const float pl = exp10f(p10);                        // float32 pow, as NumPy evaluates 10**float32
         double pw;
         if (iso) {
             pw = (double)pl;
@@ -181,7 +197,8 @@ __global__ __launch_bounds__(256) void k1_path_prep(PrepArgs a) {
         if (used && !isnan(delay)) { maxd = fmaxf(maxd, delay); any_delay = true; }
         const bool valid = used && !isnan(pw);               // channel.py:260
         const float ph32 = phase * D2R_F;                    // np.deg2rad(float32)
-        const float e_re = (float)cos((double)ph32), e_im = (float)sin((double)ph32);   // complex64 exp
+        float e_re, e_im;
+        sincosf(ph32, &e_im, &e_re);                         // complex64 exp: float32 cos / sin
         const bool ang_ok = !isnan(th_t) && !isnan(th_r);    // geometry.py:65 zeroes NaN-zenith columns
         float c_re, c_im, dn = 0.0f;
         bool keep;
@@ -226,7 +243,7 @@ __global__ __launch_bounds__(256) void k1_path_prep(PrepArgs a) {
             ty = a.bs_spacing * (sin(th_t) * sin(ph_t)); tz = a.bs_spacing * cos(th_t);
             ry = a.ue_spacing * (sin(th_r) * sin(ph_r)); rz = a.ue_spacing * cos(th_r);
         }
-        const unsigned long long kb = __ballot(keep);
+        const unsigned long long kb = group_mask<LPU>(__ballot(keep), grp);
         if (keep) {
             const int slot = keep_base + __popcll(kb & ((1ull << lane) - 1ull));
             a.ws.c_re[wrow + slot] = c_re; a.ws.c_im[wrow + slot] = c_im; a.ws.dn[wrow + slot] = dn;
@@ -240,9 +257,9 @@ __global__ __launch_bounds__(256) void k1_path_prep(PrepArgs a) {
     }
 
     // wave reductions
-    for (int off = 32; off > 0; off >>= 1) maxd = fmaxf(maxd, __shfl_xor(maxd, off));
-    const bool anyd = __ballot(any_delay) != 0ull;
-    if (lane == 0) {
+    for (int off = LPU / 2; off > 0; off >>= 1) maxd = fmaxf(maxd, __shfl_xor(maxd, off, LPU));
+    const bool anyd = group_mask<LPU>(__ballot(any_delay), grp) != 0ull;
+    if (lane == 0 && u_ok) {
         a.ws.n_keep[u] = keep_base;
         if (a.side.num_paths) a.side.num_paths[u] = count_paths;
         if (a.side.los) {
@@ -272,8 +289,13 @@ int launch_path_prep(const dmx_rays& rays, const dmx_params& prm, const WsView& 
     a.ts32 = (float)(1.0 / prm.bandwidth);
     a.doppler = prm.enable_doppler; a.fc = prm.carrier_freq; a.rx_filter = prm.rx_filter && prm.freq_domain;
     if (rays.n_ue == 0) return DMX_OK;
-    const unsigned grid = (unsigned)((rays.n_ue + 3) / 4);
-    hipLaunchKernelGGL(k1_path_prep, dim3(grid), dim3(256), 0, stream, a);
+    if (rays.n_paths <= 32) {
+        const unsigned grid = (unsigned)((rays.n_ue + 7) / 8);
+        hipLaunchKernelGGL(k1_path_prep<32>, dim3(grid), dim3(256), 0, stream, a);
+    } else {
+        const unsigned grid = (unsigned)((rays.n_ue + 3) / 4);
+        hipLaunchKernelGGL(k1_path_prep<64>, dim3(grid), dim3(256), 0, stream, a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("k1_path_prep launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
     return DMX_OK;

@@ -56,6 +56,12 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(x - (float)hi);
 }
 
+template <bool NT>
+__device__ __forceinline__ void store_out(float* p, float v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
+template <bool NT>
 __global__ __launch_bounds__(256, 2) void k2_fd_mfma(WsView ws, MfmaArgs a, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Ahi = smem;                                          // [rows][144 B]
@@ -198,13 +204,13 @@ __global__ __launch_bounds__(256, 2) void k2_fd_mfma(WsView ws, MfmaArgs a, floa
                 if (kok) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i)
-                        tb[(unsigned)((i & 3) + 8 * (i >> 2)) * (unsigned)twoK + lane_off] = acc[i] * oscale;
+                        store_out<NT>(tb + ((unsigned)((i & 3) + 8 * (i >> 2)) * (unsigned)twoK + lane_off), acc[i] * oscale);
                 }
             } else if (kok) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-                    if (row < rows_left) tb[(unsigned)((i & 3) + 8 * (i >> 2)) * (unsigned)twoK + lane_off] = acc[i] * oscale;
+                    if (row < rows_left) store_out<NT>(tb + ((unsigned)((i & 3) + 8 * (i >> 2)) * (unsigned)twoK + lane_off), acc[i] * oscale);
                 }
             }
         }
@@ -222,7 +228,7 @@ bool fd_mfma_preferred(const dmx_params& prm, const WsView& ws) {
 }
 
 int launch_channels_fd_mfma(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
-                            float2* out, hipStream_t stream) {
+                            float2* out, bool nontemporal, hipStream_t stream) {
     MfmaArgs a;
     a.user_begin = user_begin;
     a.m_rx = prm.ue_shape[0] * prm.ue_shape[1];
@@ -237,14 +243,18 @@ int launch_channels_fd_mfma(const dmx_params& prm, const WsView& ws, int64_t use
     const int mrows = a.M < MAX_ROWS ? a.M : MAX_ROWS;
     a.rows = (mrows + 31) / 32 * 32;
     const size_t smem = (size_t)2 * a.rows * ROW_BYTES + LPAD * (8 + 4 + 4) + 16;
+    const void* kfn = nontemporal ? reinterpret_cast<const void*>(k2_fd_mfma<true>) : reinterpret_cast<const void*>(k2_fd_mfma<false>);
     if (smem > 64 * 1024) {     // per device and cheap: no cached flag, so every GPU of a process gets it
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k2_fd_mfma),
+        hipError_t e = hipFuncSetAttribute(kfn,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MAX_ROWS * ROW_BYTES + 1024);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
     }
     const int64_t blocks = user_count * a.nblk;
     if (blocks > 0x7fffffffLL) { set_error("too many workgroups for one call"); return DMX_ERR_SHAPE; }
-    hipLaunchKernelGGL(k2_fd_mfma, dim3((unsigned)blocks), dim3(256), smem, stream, ws, a, reinterpret_cast<float*>(out));
+    if (nontemporal)
+        hipLaunchKernelGGL(k2_fd_mfma<true>, dim3((unsigned)blocks), dim3(256), smem, stream, ws, a, reinterpret_cast<float*>(out));
+    else
+        hipLaunchKernelGGL(k2_fd_mfma<false>, dim3((unsigned)blocks), dim3(256), smem, stream, ws, a, reinterpret_cast<float*>(out));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("k2_fd_mfma launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
     return DMX_OK;

@@ -79,9 +79,29 @@ def test_golden(name, variant, capsys):
     assert ds.power_linear.dtype == ref["power_linear"].dtype
     g = ds["_power_linear_ant_gain"]
     assert g.dtype == ref["power_linear_ant_gain"].dtype
-    np.testing.assert_allclose(g, ref["power_linear_ant_gain"], rtol=2e-6, atol=1e-30, equal_nan=True)
-    for k in ("aod_el_rot", "aod_az_rot", "aoa_el_rot", "aoa_az_rot"):
-        np.testing.assert_allclose(ds["_" + k], ref[k], rtol=0, atol=2e-6, equal_nan=True)
+    # isotropic: the same float32 value as power_linear.  Dipole: the gain cos^2(pi/2 cos t)/sin t is
+    # ill-conditioned near its nulls, where the ~1e-7 rad float32-trig difference of the rotated zenith
+    # angle is amplified; bound it relative to the un-attenuated path power.
+    iso = case["bs_pattern"] == "isotropic" and case["ue_pattern"] == "isotropic"
+    if iso:
+        np.testing.assert_allclose(g, ref["power_linear_ant_gain"], rtol=2e-6, atol=1e-30, equal_nan=True)
+    else:
+        err = np.abs(g - ref["power_linear_ant_gain"])
+        bound = 2e-6 * 1.643 ** 2 * ref["power_linear"].astype(np.float64) + 5e-5 * np.abs(ref["power_linear_ant_gain"])
+        assert np.array_equal(np.isnan(g), np.isnan(ref["power_linear_ant_gain"]))
+        assert np.all(err[~np.isnan(err)] <= bound[~np.isnan(err)])
+    # Rotated angles: arccos / atan2 of float32-rounded sin/cos are ill-conditioned towards the rotated
+    # poles (d angle = d arg / sin(zenith)); the float32 sin/cos of NumPy's SIMD loops and of the GPU
+    # differ by an ulp in ~10 % of inputs, so compare conditioned by sin(zenith).
+    for side in ("aod", "aoa"):
+        zen_ref, az_ref = ref[side + "_el_rot"], ref[side + "_az_rot"]
+        zen, az = ds[f"_{side}_el_rot"], ds[f"_{side}_az_rot"]
+        assert np.array_equal(np.isnan(zen), np.isnan(zen_ref)) and np.array_equal(np.isnan(az), np.isnan(az_ref))
+        w = np.maximum(np.abs(np.sin(zen_ref)), 1e-3)
+        daz = np.abs(np.angle(np.exp(1j * (az - az_ref))))
+        ok = ~np.isnan(zen_ref)
+        assert np.all(np.abs(zen - zen_ref)[ok] * w[ok] <= 1e-6)
+        assert np.all(daz[ok] * w[ok] <= 1e-6)
     if case["freq_domain"]:
         warned = "exceed OFDM symbol duration" in capsys.readouterr().out
         assert warned == bool(ref["warned"])
