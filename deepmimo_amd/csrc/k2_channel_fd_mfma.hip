@@ -17,15 +17,16 @@
 // loss stays below 1e-6 of the user's peak; the epilogue multiplies the exact inverse power of two
 // back.  Measured error vs the fp64-accumulating reference: ~2e-6 of the user's peak (tolerance 5e-5).
 //
-// Mapping (one 256-thread workgroup = one user x one block of <= 256 antenna pairs):
+// Mapping (one 1024-thread workgroup = one user x one block of <= 256 antenna pairs):
 //   phase 1  all threads: A' hi/lo tiles -> LDS (row = pair, 64 f16 of kk + 16 B pad: the 144-B row
 //            stride makes the ds_read_b128 fragment reads bank-conflict-free).
 //   phase 2  each wave owns 32-column strips (16 subcarriers, re/im interleaved).  Lane = column:
 //            it builds its own B' fragments in registers (lane pairs 2k/2k+1 split the sincos work
 //            and swap results with one DPP-style shuffle), then walks the 32-row tiles:
-//            8 ds_read_b128 + 12 v_mfma_f32_32x32x16_f16 + 16 global_store_dword per tile.  The
+//            8 ds_read_b128 + 12 v_mfma_f32_32x32x16_f16 + 16 buffer_store_dword (nt) per tile.  The
 //            32x32 accumulator has its column on the lane, so every store instruction writes two
-//            contiguous 128-B row segments of the output - no LDS transpose, no shuffles.
+//            contiguous 128-B row segments of the output - no LDS transpose, no shuffles; the row is
+//            a scalar offset of the buffer instruction, so the epilogue is 1 VALU op per store.
 // HBM traffic = the 8*M*K output bytes (written once) + ~1 KB of path records per user.
 #include "dmx_common.h"
 
@@ -51,18 +52,22 @@ struct MfmaArgs {
     int rows;        // LDS rows (multiple of 32)
 };
 
-__device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
-    hi = (_Float16)x;
-    lo = (_Float16)(x - (float)hi);
+// (x0, x1) -> packed hi pair and packed lo pair, x = hi + lo.  v_cvt_pkrtz_f16_f32 converts two floats per
+// instruction; with round-toward-zero x - hi is exact in fp32 and lo keeps 11 more bits of it.
+typedef __fp16 hp2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2_f16(float x0, float x1, h2& hi, h2& lo) {
+    const hp2 h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+    const hp2 l = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
+    hi = __builtin_bit_cast(h2, h);
+    lo = __builtin_bit_cast(h2, l);
 }
 
-template <bool NT>
-__device__ __forceinline__ void store_out(float* p, float v) {
-    if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
-}
-
-template <bool NT>
-__global__ __launch_bounds__(256, 2) void k2_fd_mfma(WsView ws, MfmaArgs a, float* __restrict__ out) {
+// NW = waves per workgroup (4, 8 or 16): the A' tiles in LDS are shared by all of them, so more waves per
+// workgroup mean more waves in flight per CU (LDS, not registers, limits occupancy here: 74 KB per
+// workgroup -> 2 workgroups per CU).  Measured at the headline config: 19.4 / 19.0 / 18.4 ms for 4 / 8 / 16.
+template <bool NT, int NW>
+__global__ __launch_bounds__(NW * 64) void k2_fd_mfma(WsView ws, MfmaArgs a, float* __restrict__ out) {
+    constexpr int NTHR = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Ahi = smem;                                          // [rows][144 B]
     unsigned char* Alo = smem + (size_t)a.rows * ROW_BYTES;
@@ -83,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void k2_fd_mfma(WsView ws, MfmaArgs a, floa
     n_act = n_act < LPAD ? n_act : LPAD;
     if (n_act == 0) {                                                    // channel.py:270-271
         const size_t nel = (size_t)nrows * twoK;
-        for (size_t i = tid; i < nel; i += 256) o[i] = 0.f;
+        for (size_t i = tid; i < nel; i += NTHR) o[i] = 0.f;
         return;
     }
     const size_t rb = (size_t)u * ws.P;
@@ -105,38 +110,40 @@ __global__ __launch_bounds__(256, 2) void k2_fd_mfma(WsView ws, MfmaArgs a, floa
         if (lane == 0) misc[0] = ldexpf(1.0f, e - 10 - 6);              // 1 / (gs * A_SCALE)
     }
 
-    // phase 1: A' tiles.  thread = row (antenna pair), loop over path slots
-    for (int r = tid; r < a.rows; r += 256) {
-        const int p = row0 + r;
-        const bool pok = p < a.M;
-        const int rx = pok ? p / a.m_tx : 0, tx = pok ? p - rx * a.m_tx : 0;
-        const double yr = (double)(rx % a.ue_mh), zr = (double)(rx / a.ue_mh);
-        const double yt = (double)(tx % a.bs_mh), zt = (double)(tx / a.bs_mh);
-        h2* rhi = reinterpret_cast<h2*>(Ahi + (size_t)r * ROW_BYTES);
-        h2* rlo = reinterpret_cast<h2*>(Alo + (size_t)r * ROW_BYTES);
-        for (int l = 0; l < LPAD; ++l) {
-            h2 vh = {(_Float16)0.f, (_Float16)0.f}, vl = vh;
-            if (pok && l < n_act) {
-                const double ph = yr * ws.rx_y[rb + l] + zr * ws.rx_z[rb + l] + yt * ws.tx_y[rb + l] + zt * ws.tx_z[rb + l];
-                float s, c;
-                sincos_rev(frac_rev(ph), s, c);
-                _Float16 h0, l0, h1, l1;
-                split_f16(c * A_SCALE, h0, l0);
-                split_f16(s * A_SCALE, h1, l1);
-                vh = h2{h0, h1};
-                vl = h2{l0, l1};
+    // phase 1: A' tiles.  thread = (row = antenna pair, slice of the path slots)
+    constexpr int LSPLIT = NW / 4, LPER = LPAD / LSPLIT;
+    {
+        const int r = tid & 255, l0 = (tid >> 8) * LPER;
+        if (r < a.rows) {
+            const int p = row0 + r;
+            const bool pok = p < a.M;
+            const int rx = pok ? p / a.m_tx : 0, tx = pok ? p - rx * a.m_tx : 0;
+            const double yr = (double)(rx % a.ue_mh), zr = (double)(rx / a.ue_mh);
+            const double yt = (double)(tx % a.bs_mh), zt = (double)(tx / a.bs_mh);
+            h2* rhi = reinterpret_cast<h2*>(Ahi + (size_t)r * ROW_BYTES);
+            h2* rlo = reinterpret_cast<h2*>(Alo + (size_t)r * ROW_BYTES);
+            for (int l = l0; l < l0 + LPER; ++l) {
+                h2 vh = {(_Float16)0.f, (_Float16)0.f}, vl = vh;
+                if (pok && l < n_act) {
+                    const double ph = yr * ws.rx_y[rb + l] + zr * ws.rx_z[rb + l] + yt * ws.tx_y[rb + l] + zt * ws.tx_z[rb + l];
+                    float s, c;
+                    sincos_rev(frac_rev(ph), s, c);
+                    split2_f16(c * A_SCALE, s * A_SCALE, vh, vl);
+                }
+                rhi[l] = vh;
+                rlo[l] = vl;
             }
-            rhi[l] = vh;
-            rlo[l] = vl;
         }
     }
     __syncthreads();
     const float oscale = misc[0];
 
     const int col = lane & 31, hh = lane >> 5;
+    const unsigned row_bytes = (unsigned)twoK * 4u;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(o, 0, (int)((unsigned)nrows * row_bytes), 0x00020000);
     const int nstrips = (int)((twoK + 31) >> 5);
     const int ntiles = (nrows + 31) >> 5;
-    for (int strip = wave; strip < nstrips; strip += 4) {
+    for (int strip = wave; strip < nstrips; strip += NW) {
         const int ncol = (strip << 5) + col;                            // column of C = 2*kidx + c
         const int kidx = ncol >> 1, c = ncol & 1;
         const bool kok = (size_t)ncol < twoK;
@@ -172,16 +179,18 @@ __global__ __launch_bounds__(256, 2) void k2_fd_mfma(WsView ws, MfmaArgs a, floa
                 for (int jj = 0; jj < 4; ++jj) {
                     const float e0 = c ? gi[jj] : gr[jj];               // row 2l   : Re G (re col) / Im G (im col)
                     const float e1 = c ? gr[jj] : -gi[jj];              // row 2l+1 : -Im G        / Re G
-                    _Float16 h0, l0, h1, l1;
-                    split_f16(e0, h0, l0);
-                    split_f16(e1, h1, l1);
-                    Bhi[s][2 * jj] = h0; Bhi[s][2 * jj + 1] = h1;
-                    Blo[s][2 * jj] = l0; Blo[s][2 * jj + 1] = l1;
+                    h2 ph, pl2;
+                    split2_f16(e0, e1, ph, pl2);
+                    Bhi[s][2 * jj] = ph[0]; Bhi[s][2 * jj + 1] = ph[1];
+                    Blo[s][2 * jj] = pl2[0]; Blo[s][2 * jj + 1] = pl2[1];
                 }
             }
         }
 
-        const unsigned lane_off = (unsigned)(4 * hh) * (unsigned)twoK + (unsigned)ncol;
+        // Output through a buffer descriptor over this workgroup's row block: the per-lane part of the
+        // address is one 32-bit voffset per strip, the row of each store is a scalar soffset, and rows
+        // past the block end fall outside num_records and are dropped by the hardware range check.
+        const unsigned lane_off = ((unsigned)(4 * hh) * (unsigned)twoK + (unsigned)ncol) * 4u;
         for (int pt = 0; pt < ntiles; ++pt) {
             f16v acc;
 #pragma unroll
@@ -198,19 +207,12 @@ __global__ __launch_bounds__(256, 2) void k2_fd_mfma(WsView ws, MfmaArgs a, floa
                 }
             }
             // 32x32 accumulator: column on the lane, register i is row (i&3) + 8*(i>>2) + 4*(lane>>5)
-            float* __restrict__ tb = o + (size_t)(pt << 5) * twoK;      // wave-uniform tile base
-            const int rows_left = nrows - (pt << 5);
-            if (rows_left >= 32) {
-                if (kok) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        store_out<NT>(tb + ((unsigned)((i & 3) + 8 * (i >> 2)) * (unsigned)twoK + lane_off), acc[i] * oscale);
-                }
-            } else if (kok) {
+            if (kok) {
+                const unsigned tile_off = (unsigned)(pt << 5) * row_bytes;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-                    if (row < rows_left) store_out<NT>(tb + ((unsigned)((i & 3) + 8 * (i >> 2)) * (unsigned)twoK + lane_off), acc[i] * oscale);
+                    const unsigned soff = tile_off + (unsigned)((i & 3) + 8 * (i >> 2)) * row_bytes;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[i] * oscale), orsrc, lane_off, soff, NT ? 2 : 0);
                 }
             }
         }
@@ -227,8 +229,21 @@ bool fd_mfma_preferred(const dmx_params& prm, const WsView& ws) {
     return fd_mfma_supported(prm, ws) && M >= 24 && prm.n_selected >= 8;
 }
 
+template <bool NT, int NW>
+static int launch_mfma_t(const WsView& ws, const MfmaArgs& a, int64_t blocks, size_t smem, float2* out, hipStream_t stream) {
+    const void* kfn = reinterpret_cast<const void*>(k2_fd_mfma<NT, NW>);
+    if (smem > 64 * 1024) {     // per device and cheap: no cached flag, so every GPU of a process gets it
+        hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MAX_ROWS * ROW_BYTES + 1024);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
+    }
+    hipLaunchKernelGGL((k2_fd_mfma<NT, NW>), dim3((unsigned)blocks), dim3(NW * 64), smem, stream, ws, a, reinterpret_cast<float*>(out));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("k2_fd_mfma launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
+    return DMX_OK;
+}
+
 int launch_channels_fd_mfma(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
-                            float2* out, bool nontemporal, hipStream_t stream) {
+                            float2* out, bool nontemporal, int nwaves, hipStream_t stream) {
     MfmaArgs a;
     a.user_begin = user_begin;
     a.m_rx = prm.ue_shape[0] * prm.ue_shape[1];
@@ -243,21 +258,13 @@ int launch_channels_fd_mfma(const dmx_params& prm, const WsView& ws, int64_t use
     const int mrows = a.M < MAX_ROWS ? a.M : MAX_ROWS;
     a.rows = (mrows + 31) / 32 * 32;
     const size_t smem = (size_t)2 * a.rows * ROW_BYTES + LPAD * (8 + 4 + 4) + 16;
-    const void* kfn = nontemporal ? reinterpret_cast<const void*>(k2_fd_mfma<true>) : reinterpret_cast<const void*>(k2_fd_mfma<false>);
-    if (smem > 64 * 1024) {     // per device and cheap: no cached flag, so every GPU of a process gets it
-        hipError_t e = hipFuncSetAttribute(kfn,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MAX_ROWS * ROW_BYTES + 1024);
-        if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
-    }
     const int64_t blocks = user_count * a.nblk;
     if (blocks > 0x7fffffffLL) { set_error("too many workgroups for one call"); return DMX_ERR_SHAPE; }
-    if (nontemporal)
-        hipLaunchKernelGGL(k2_fd_mfma<true>, dim3((unsigned)blocks), dim3(256), smem, stream, ws, a, reinterpret_cast<float*>(out));
-    else
-        hipLaunchKernelGGL(k2_fd_mfma<false>, dim3((unsigned)blocks), dim3(256), smem, stream, ws, a, reinterpret_cast<float*>(out));
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { set_error("k2_fd_mfma launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
-    return DMX_OK;
+    if (nwaves == 16) return launch_mfma_t<true, 16>(ws, a, blocks, smem, out, stream);
+    if (nwaves == 8) return nontemporal ? launch_mfma_t<true, 8>(ws, a, blocks, smem, out, stream)
+                                        : launch_mfma_t<false, 8>(ws, a, blocks, smem, out, stream);
+    return nontemporal ? launch_mfma_t<true, 4>(ws, a, blocks, smem, out, stream)
+                       : launch_mfma_t<false, 4>(ws, a, blocks, smem, out, stream);
 }
 
 }  // namespace dmx

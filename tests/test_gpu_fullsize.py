@@ -1,0 +1,119 @@
+"""GPU tests at BASELINE.json's full single-GPU sizes (config 2: 10k users x 32x4 x 10 paths x 256 sc;
+config 3 = headline: 100k users x 64x4 x 25 paths x 512 sc, 104.9 GB of output), through the C-ABI.
+
+The oracle cannot run these sizes (the reference itself cannot: SURVEY.md section 6), so parity is
+checked through size-independent properties plus an oracle comparison on a user sample:
+  * sample parity      - 48 users spread over the shard vs the NumPy oracle (tolerance 5e-5 of peak)
+  * shard invariance   - generating a user sub-range [a, b) alone is BIT-identical to the same rows of
+                         the full launch (what multi-GPU sharding relies on)
+  * path permutation   - permuting a user's paths leaves H unchanged up to fp32 summation order
+  * zero users         - users without valid paths are exactly zero; everything is finite
+  * kernel agreement   - MFMA (variant 2) and fp32 vector (variant 1) kernels agree within tolerance
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests._cases import assert_channel_close
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    "c2": dict(n_ue=10_000, bs=[8, 4], ue=[2, 2], L=10, N=256),
+    "c3": dict(n_ue=100_000, bs=[8, 8], ue=[2, 2], L=25, N=512),
+}
+
+
+def _setup(cfg, seed=2024):
+    import deepmimo_amd as dm
+    from deepmimo_amd.engine import ChannelEngine
+    from oracle import oracle_np as onp
+    w = CONFIGS[cfg]
+    free, _ = torch.cuda.mem_get_info()
+    m = w["ue"][0] * w["ue"][1] * w["bs"][0] * w["bs"][1]
+    need = w["n_ue"] * m * w["N"] * 8
+    if need * 1.15 > free:
+        pytest.skip(f"needs {need/1e9:.0f} GB of HBM, {free/1e9:.0f} GB free")
+    rays = onp.synth_rays(w["n_ue"], w["L"], seed=seed)          # ragged: 0..L valid paths per user
+    p = dm.ChannelGenParameters()
+    p.bs_antenna.shape = np.array(w["bs"])
+    p.ue_antenna.shape = np.array(w["ue"])
+    p.bs_antenna.rotation = np.array([5, -10, 20])
+    p.num_paths = w["L"]
+    p.ofdm.subcarriers = w["N"]
+    p.ofdm.selected_subcarriers = np.arange(w["N"])
+    p.validate(w["n_ue"])
+    op = onp.make_params(bs_antenna=dict(shape=w["bs"], rotation=np.array([5, -10, 20])), ue_antenna=dict(shape=w["ue"]),
+                         num_paths=w["L"], ofdm=dict(subcarriers=w["N"], selected_subcarriers=np.arange(w["N"])))
+    eng = ChannelEngine(0)
+    return w, rays, p, op, eng, onp
+
+
+@pytest.mark.parametrize("cfg", ["c2", "c3"])
+def test_full_size_properties(cfg):
+    w, rays, p, op, eng, onp = _setup(cfg)
+    n = w["n_ue"]
+    dr = eng.upload_rays(rays)
+    prep = eng.prepare(dr, p, want_side=True)
+    H = eng.channels(prep)                                        # default kernel, whole shard in one launch
+    torch.cuda.synchronize()
+    assert H.shape == (n, 4, w["bs"][0] * w["bs"][1], w["N"]) and H.dtype == torch.complex64
+
+    # sample parity vs the oracle
+    idx = np.unique(np.concatenate([np.arange(0, n, max(1, n // 40)), [n - 1, n - 2, 1]]))[:48]
+    sub = {k: rays[k][idx] for k in onp.RAY_KEYS}
+    ref = onp.compute_channels(sub, op)
+    worst = assert_channel_close(H[torch.from_numpy(idx).cuda()].cpu().numpy(), ref["channel"], what=f"{cfg} sample")
+    assert worst < 5e-5
+    np.testing.assert_array_equal(prep.side["los"].cpu().numpy()[idx], ref["los"])
+    np.testing.assert_array_equal(prep.side["num_paths"].cpu().numpy()[idx], ref["num_paths"])
+
+    # users without any valid path are exactly zero (channel.py:270-271); everything finite
+    nvalid = (~np.isnan(rays["power"])).sum(axis=1)
+    zero_users = torch.from_numpy(np.nonzero(nvalid == 0)[0][:64]).cuda()
+    assert zero_users.numel() > 0
+    assert float(torch.view_as_real(H[zero_users]).abs().max()) == 0.0
+    step = max(1, n // 2000)
+    assert bool(torch.isfinite(torch.view_as_real(H[::step])).all())
+    assert float(torch.view_as_real(H[::step]).abs().max()) > 0.0
+
+    # shard invariance: a sub-range generated alone is bit-identical
+    for a, b in ((0, 257), (n // 3, n // 3 + 1000), (n - 513, n)):
+        part = eng.channels(prep, user_begin=a, user_count=b - a)
+        assert torch.equal(torch.view_as_real(part), torch.view_as_real(H[a:b])), (a, b)
+        del part
+
+    # kernel agreement on a block of users
+    a, b = n // 2, n // 2 + 512
+    v1 = eng.channels(prep, user_begin=a, user_count=b - a, variant=1).cpu().numpy()
+    assert_channel_close(H[a:b].cpu().numpy(), v1, what=f"{cfg} mfma vs fp32 vector")
+
+    # path permutation invariance (first 2000 users)
+    m = min(n, 2000)
+    rng = np.random.default_rng(5)
+    perm_rays = {}
+    perm = np.argsort(rng.uniform(size=(m, w["L"])), axis=1)
+    for k in onp.RAY_KEYS:
+        perm_rays[k] = np.take_along_axis(rays[k][:m], perm, axis=1)
+    prep2 = eng.prepare(eng.upload_rays(perm_rays), p, want_side=True)
+    H2 = eng.channels(prep2).cpu().numpy()
+    assert_channel_close(H2, H[:m].cpu().numpy(), tol_rel=2e-6, what=f"{cfg} path permutation")
+    np.testing.assert_array_equal(prep2.side["num_paths"].cpu().numpy(), prep.side["num_paths"].cpu().numpy()[:m])
+
+
+def test_sharded_driver_matches_dataset():
+    """deepmimo_amd.dist.compute_channels_sharded at world size 1 == Dataset.compute_channels."""
+    import deepmimo_amd as dm
+    from deepmimo_amd import dist as ddist
+    from oracle import oracle_np as onp
+    rays = onp.synth_rays(300, 12, seed=11)
+    p = dm.ChannelGenParameters()
+    p.bs_antenna.shape = np.array([4, 4])
+    p.ue_antenna.shape = np.array([2, 1])
+    p.ofdm.selected_subcarriers = np.arange(0, 512, 8)
+    ds = dm.Dataset(dict(rays))
+    H = ds.compute_channels(p)
+    res = ddist.compute_channels_sharded(rays, p.validate(300))
+    assert (res.user_begin, res.user_end, res.n_total) == (0, 300, 300)
+    assert np.array_equal(res.channel.cpu().numpy(), H)
+    assert np.array_equal(res.side["los"].cpu().numpy(), ds.los)

@@ -47,7 +47,7 @@ def _dataset(case, rays, with_doppler=False):
     return ds
 
 
-@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("variant", [1, 0, 4, 5])
 @pytest.mark.parametrize("name", golden_names())
 def test_golden(name, variant, capsys):
     import deepmimo_amd as dm
@@ -134,7 +134,7 @@ SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("variant", [1, 0, 4, 5])
 @pytest.mark.parametrize("shape", SHAPES, ids=[f"s{i}" for i in range(len(SHAPES))])
 def test_vs_oracle_shapes(shape, variant):
     """Seeded synthetic rays at ragged shapes (K not a multiple of 64, odd panels, 1..32 paths)."""
