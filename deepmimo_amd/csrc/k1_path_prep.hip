@@ -50,13 +50,45 @@ static constexpr double TWO_PI = 6.283185307179586;
 static constexpr double HALF_PI = 1.5707963267948966;
 static constexpr double LIGHTSPEED = 299792458.0;           // deepmimo_v3/consts.py:112
 
+// NumPy's float32 sin / cos (the SIMD loops np.sin / np.cos dispatch to for float32 arrays on x86
+// with FMA): Cody-Waite reduction by pi/2 in three float32 constants, degree-9 / degree-8 minimax
+// polynomials, all in float32 FMAs.  The zenith sin/cos feed arccos / atan2, which amplify a
+// 1-ulp float32 difference by 1/sin(zenith) towards the rotated poles, so K1 reproduces that
+// routine operation for operation; validated bit-for-bit against np.sin / np.cos on 2e6 inputs
+// (tests/test_oracle_golden.py::test_numpy_f32_sincos_model).  |x| beyond the routine's range
+// (7e4) falls back to sinf / cosf like NumPy falls back to libm.
+__device__ __forceinline__ void np_sincosf(float x, float& s_out, float& c_out) {
+    if (!(fabsf(x) <= 71476.0625f)) { s_out = sinf(x); c_out = cosf(x); return; }
+    float q = x * 0x1.45f306p-1f;
+    q = (q + 0x1.8p+23f) - 0x1.8p+23f;                       // round to nearest integer
+    float r = fmaf(q, -0x1.921fb0p+00f, x);
+    r = fmaf(q, -0x1.5110b4p-22f, r);
+    r = fmaf(q, -0x1.846988p-48f, r);
+    const float r2 = r * r;
+    float sp = fmaf(0x1.7d3bbcp-19f, r2, -0x1.a06bbap-13f);
+    sp = fmaf(sp, r2, 0x1.11119ap-07f);
+    sp = fmaf(sp, r2, -0x1.555556p-03f);
+    sp = fmaf(sp, r2, 0.0f);
+    sp = fmaf(sp, r, r);
+    float cp = fmaf(0x1.98e616p-16f, r2, -0x1.6c06dcp-10f);
+    cp = fmaf(cp, r2, 0x1.55553cp-05f);
+    cp = fmaf(cp, r2, -0.5f);
+    cp = fmaf(cp, r2, 1.0f);
+    const int iq = (int)q;
+    const int iqc = iq + 1;
+    float sv = (iq & 1) ? cp : sp;
+    float cv = (iqc & 1) ? cp : sp;
+    s_out = (iq & 2) ? -sv : sv;
+    c_out = (iqc & 2) ? -cv : cv;
+}
+
 // geometry.py:284-310 for one path
 __device__ __forceinline__ void rotate_one(float el_deg, float az_deg, double sx, double cx, double sy,
                                            double cy, double rz, double& th, double& ph) {
     const float th32 = el_deg * D2R_F;
     const float ph32 = az_deg * D2R_F;
     float st32, ct32;
-    sincosf(th32, &st32, &ct32);                            // np.sin / np.cos of float32 stay float32
+    np_sincosf(th32, st32, ct32);                           // np.sin / np.cos of float32 stay float32
     const double st = (double)st32, ct = (double)ct32;
     const double d = (double)ph32 - rz;
     double sd, cd;

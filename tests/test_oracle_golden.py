@@ -114,3 +114,40 @@ def test_empty_and_all_nan_inputs():
     assert np.all(res["channel"] == 0)
     assert res["los"].tolist() == [-1, -1, -1]
     assert res["num_paths"].tolist() == [0, 0, 0]
+
+
+def test_numpy_f32_sincos_model():
+    """K1 reproduces NumPy's float32 sin/cos routine (csrc/k1_path_prep.hip: np_sincosf).  This pins the
+    model of that routine - same constants, same operation order - to np.sin / np.cos bit for bit, so a
+    NumPy whose float32 loops changed would be noticed here rather than as drifting rotated angles."""
+    f32 = np.float32
+
+    def fma(a, b, c):      # float32 FMA emulated through float64 (exact product + one rounding)
+        return (a.astype(np.float64) * np.float64(b) + np.asarray(c, dtype=np.float64)).astype(f32)
+
+    def H(s):
+        return f32(float.fromhex(s))
+
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-np.pi, np.pi, 400_000), rng.uniform(0, np.pi, 100_000),
+                        np.deg2rad(np.arange(0, 181, dtype=f32))]).astype(f32)
+    q = (x * H("0x1.45f306p-1")).astype(f32)
+    q = ((q + H("0x1.8p+23")).astype(f32) - H("0x1.8p+23")).astype(f32)
+    r = fma(q, H("-0x1.921fb0p+00"), x)
+    r = fma(q, H("-0x1.5110b4p-22"), r)
+    r = fma(q, H("-0x1.846988p-48"), r)
+    r2 = (r * r).astype(f32)
+    sp = fma(r2, H("0x1.7d3bbcp-19"), H("-0x1.a06bbap-13"))
+    for cst in ("0x1.11119ap-07", "-0x1.555556p-03"):
+        sp = (sp.astype(np.float64) * r2.astype(np.float64) + np.float64(H(cst))).astype(f32)
+    sp = (sp.astype(np.float64) * r2.astype(np.float64)).astype(f32)
+    sp = (sp.astype(np.float64) * r.astype(np.float64) + r.astype(np.float64)).astype(f32)
+    cp = fma(r2, H("0x1.98e616p-16"), H("-0x1.6c06dcp-10"))
+    for cst in ("0x1.55553cp-05", "-0x1.000000p-01", "0x1.000000p+00"):
+        cp = (cp.astype(np.float64) * r2.astype(np.float64) + np.float64(H(cst))).astype(f32)
+    iq = q.astype(np.int64)
+    sin_m = np.where(iq & 2, -np.where(iq & 1, cp, sp), np.where(iq & 1, cp, sp)).astype(f32)
+    iqc = iq + 1
+    cos_m = np.where(iqc & 2, -np.where(iqc & 1, cp, sp), np.where(iqc & 1, cp, sp)).astype(f32)
+    assert np.array_equal(sin_m, np.sin(x))
+    assert np.array_equal(cos_m, np.cos(x))
