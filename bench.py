@@ -86,6 +86,21 @@ def cpu_baseline(w, sample_users):
                       f"host has {os.cpu_count()} logical cores"}
 
 
+def measured_traffic(workload, n_ue, variant):
+    """HBM bytes per stage-2 launch from the committed rocprofv3 PMC passes (profiles/traffic.json:
+    WRITE_SIZE + 2 x FETCH_SIZE in KiB, separate --pmc runs, gfx950 FETCH correction applied).  Only
+    reported when the profiled run matches this run's workload, user count and kernel variant."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        e = t.get(workload)
+        if e and e["users"] == n_ue and e["variant"] == variant:
+            return e["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,7 +191,7 @@ def main():
                    "fd_kernel_variant": args.variant,
                    "complex_macs_per_s": cmacs * world / (elapsed / max(args.steps, 1))},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, n_ue, args.variant),
                      "kernel": "stage-2 contraction (k2_fd_*)", "kernel_ms": k2_ms,
                      "algorithmic_bytes_per_launch": n_ue * bytes_per_user},
     }

@@ -221,7 +221,7 @@ static int launch_fd_valu_any(const dmx_params& prm, const WsView& ws, int64_t u
 }
 
 int launch_channels_fd_mfma(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
-                            float2* out, bool nontemporal, int nwaves, hipStream_t stream);
+                            float2* out, int config, hipStream_t stream);
 bool fd_mfma_supported(const dmx_params& prm, const WsView& ws);
 bool fd_mfma_preferred(const dmx_params& prm, const WsView& ws);
 
@@ -233,7 +233,7 @@ int launch_channels_fd(const dmx_params& prm, const WsView& ws, int64_t user_beg
         return DMX_ERR_SHAPE;
     }
     if (variant >= 2 || (variant == 0 && fd_mfma_preferred(prm, ws)))
-        return launch_channels_fd_mfma(prm, ws, user_begin, user_count, out, variant != 3, variant == 4 ? 4 : (variant == 5 ? 8 : 16), stream);
+        return launch_channels_fd_mfma(prm, ws, user_begin, user_count, out, variant >= 3 ? variant - 2 : 0, stream);
     return launch_fd_valu_any(prm, ws, user_begin, user_count, nullptr, out, stream);
 }
 

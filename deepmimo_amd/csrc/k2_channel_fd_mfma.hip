@@ -62,10 +62,57 @@ __device__ __forceinline__ void split2_f16(float x0, float x1, h2& hi, h2& lo) {
     lo = __builtin_bit_cast(h2, l);
 }
 
+// B' fragments of one lane for strip `strip` (32 columns = 16 subcarriers, re/im interleaved): element j of
+// K-step s is row kk = 16s + 8h + j of B', i.e. path l = 8s + 4h + (j>>1), component j&1.
+__device__ __forceinline__ void gen_b_fragments(int strip, int col, int hh, size_t twoK, const int32_t* __restrict__ sc,
+                                                int n_act, const double* qtab, const float* crtab, const float* citab,
+                                                h8 (&Bhi)[4], h8 (&Blo)[4], bool& kok, unsigned& lane_off) {
+    const int ncol = (strip << 5) + col;                                // column of C = 2*kidx + c
+    const int kidx = ncol >> 1, c = ncol & 1;
+    kok = (size_t)ncol < twoK;
+    lane_off = ((unsigned)(4 * hh) * (unsigned)twoK + (unsigned)ncol) * 4u;
+    const double kk = (double)(kok ? sc[kidx] : 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        Bhi[s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+        Blo[s] = Bhi[s];
+        if (8 * s < n_act) {
+            // this lane evaluates paths jj = 2c, 2c+1 of the step, its pair lane (same subcarrier,
+            // other re/im column) the other two; swap through a lane-pair shuffle
+            float mr[2], mi[2], orr[2], oi[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int pl = 8 * s + 4 * hh + 2 * c + t;
+                float sn, cs;
+                sincos_rev(frac_rev(qtab[pl] * kk), sn, cs);
+                const float cr = crtab[pl], ci = citab[pl];
+                mr[t] = cr * cs + ci * sn;                              // Re c*exp(-j x)
+                mi[t] = ci * cs - cr * sn;                              // Im
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { orr[t] = __shfl_xor(mr[t], 1); oi[t] = __shfl_xor(mi[t], 1); }
+            float gr[4], gi[4];
+            gr[0] = c ? orr[0] : mr[0]; gi[0] = c ? oi[0] : mi[0];
+            gr[1] = c ? orr[1] : mr[1]; gi[1] = c ? oi[1] : mi[1];
+            gr[2] = c ? mr[0] : orr[0]; gi[2] = c ? mi[0] : oi[0];
+            gr[3] = c ? mr[1] : orr[1]; gi[3] = c ? mi[1] : oi[1];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float e0 = c ? gi[jj] : gr[jj];                   // row 2l   : Re G (re col) / Im G (im col)
+                const float e1 = c ? gr[jj] : -gi[jj];                  // row 2l+1 : -Im G        / Re G
+                h2 ph, pl2;
+                split2_f16(e0, e1, ph, pl2);
+                Bhi[s][2 * jj] = ph[0]; Bhi[s][2 * jj + 1] = ph[1];
+                Blo[s][2 * jj] = pl2[0]; Blo[s][2 * jj + 1] = pl2[1];
+            }
+        }
+    }
+}
+
 // NW = waves per workgroup (4, 8 or 16): the A' tiles in LDS are shared by all of them, so more waves per
 // workgroup mean more waves in flight per CU (LDS, not registers, limits occupancy here: 74 KB per
 // workgroup -> 2 workgroups per CU).  Measured at the headline config: 19.4 / 19.0 / 18.4 ms for 4 / 8 / 16.
-template <bool NT, int NW>
+template <bool NT, int NW, int SPW>
 __global__ __launch_bounds__(NW * 64) void k2_fd_mfma(WsView ws, MfmaArgs a, float* __restrict__ out) {
     constexpr int NTHR = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -142,77 +189,52 @@ __global__ __launch_bounds__(NW * 64) void k2_fd_mfma(WsView ws, MfmaArgs a, flo
     const unsigned row_bytes = (unsigned)twoK * 4u;
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(o, 0, (int)((unsigned)nrows * row_bytes), 0x00020000);
     const int nstrips = (int)((twoK + 31) >> 5);
+    const int ngroups = (nstrips + SPW - 1) / SPW;
     const int ntiles = (nrows + 31) >> 5;
-    for (int strip = wave; strip < nstrips; strip += NW) {
-        const int ncol = (strip << 5) + col;                            // column of C = 2*kidx + c
-        const int kidx = ncol >> 1, c = ncol & 1;
-        const bool kok = (size_t)ncol < twoK;
-        const double kk = (double)(kok ? a.sc[kidx] : 0);
+    // A wave owns SPW adjacent 32-column strips at a time and walks the row tiles with all of them, so the
+    // 16 (8) waves of the workgroup fill one 32-row band of the user's block together: A' fragments are
+    // read from LDS once per tile for SPW strips and the stores of a workgroup stay within a few DRAM pages.
+    for (int grp = wave; grp < ngroups; grp += NW) {
+        h8 Bhi[SPW][4], Blo[SPW][4];
+        unsigned lane_off[SPW];
+        bool kok[SPW];
+#pragma unroll
+        for (int j = 0; j < SPW; ++j)
+            gen_b_fragments(grp * SPW + j, col, hh, twoK, a.sc, n_act, qtab, crtab, citab, Bhi[j], Blo[j], kok[j], lane_off[j]);
 
-        // B' fragments of this lane's column: element j of K-step s is row 16s + 8h + j
-        h8 Bhi[4], Blo[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            Bhi[s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
-            Blo[s] = Bhi[s];
-            if (8 * s < n_act) {
-                // this lane evaluates paths jj = 2c, 2c+1 of the step, its pair lane (same subcarrier,
-                // other re/im column) the other two; swap through a lane-pair shuffle
-                float mr[2], mi[2], orr[2], oi[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int pl = 8 * s + 4 * hh + 2 * c + t;
-                    float sn, cs;
-                    sincos_rev(frac_rev(qtab[pl] * kk), sn, cs);
-                    const float cr = crtab[pl], ci = citab[pl];
-                    mr[t] = cr * cs + ci * sn;                          // Re c*exp(-j x)
-                    mi[t] = ci * cs - cr * sn;                          // Im
-                }
-#pragma unroll
-                for (int t = 0; t < 2; ++t) { orr[t] = __shfl_xor(mr[t], 1); oi[t] = __shfl_xor(mi[t], 1); }
-                float gr[4], gi[4];
-                gr[0] = c ? orr[0] : mr[0]; gi[0] = c ? oi[0] : mi[0];
-                gr[1] = c ? orr[1] : mr[1]; gi[1] = c ? oi[1] : mi[1];
-                gr[2] = c ? mr[0] : orr[0]; gi[2] = c ? mi[0] : oi[0];
-                gr[3] = c ? mr[1] : orr[1]; gi[3] = c ? mi[1] : oi[1];
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const float e0 = c ? gi[jj] : gr[jj];               // row 2l   : Re G (re col) / Im G (im col)
-                    const float e1 = c ? gr[jj] : -gi[jj];              // row 2l+1 : -Im G        / Re G
-                    h2 ph, pl2;
-                    split2_f16(e0, e1, ph, pl2);
-                    Bhi[s][2 * jj] = ph[0]; Bhi[s][2 * jj + 1] = ph[1];
-                    Blo[s][2 * jj] = pl2[0]; Blo[s][2 * jj + 1] = pl2[1];
-                }
-            }
-        }
-
-        // Output through a buffer descriptor over this workgroup's row block: the per-lane part of the
-        // address is one 32-bit voffset per strip, the row of each store is a scalar soffset, and rows
-        // past the block end fall outside num_records and are dropped by the hardware range check.
-        const unsigned lane_off = ((unsigned)(4 * hh) * (unsigned)twoK + (unsigned)ncol) * 4u;
         for (int pt = 0; pt < ntiles; ++pt) {
-            f16v acc;
+            f16v acc[SPW];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            for (int j = 0; j < SPW; ++j)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
             const size_t abase = (size_t)((pt << 5) + col) * ROW_BYTES + (size_t)hh * 16;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 if (8 * s < n_act) {
                     const h8 ah = *reinterpret_cast<const h8*>(Ahi + abase + s * 32);
                     const h8 al = *reinterpret_cast<const h8*>(Alo + abase + s * 32);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bhi[s], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Blo[s], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bhi[s], acc, 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < SPW; ++j) {
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bhi[j][s], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Blo[j][s], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bhi[j][s], acc[j], 0, 0, 0);
+                    }
                 }
             }
-            // 32x32 accumulator: column on the lane, register i is row (i&3) + 8*(i>>2) + 4*(lane>>5)
-            if (kok) {
-                const unsigned tile_off = (unsigned)(pt << 5) * row_bytes;
+            // 32x32 accumulator: column on the lane, register i is row (i&3) + 8*(i>>2) + 4*(lane>>5).
+            // Output through a buffer descriptor over this workgroup's row block: the per-lane part of the
+            // address is one 32-bit voffset per strip, the row of each store is a scalar soffset, and rows
+            // past the block end fall outside num_records and are dropped by the hardware range check.
+            const unsigned tile_off = (unsigned)(pt << 5) * row_bytes;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const unsigned soff = tile_off + (unsigned)((i & 3) + 8 * (i >> 2)) * row_bytes;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[i] * oscale), orsrc, lane_off, soff, NT ? 2 : 0);
+            for (int j = 0; j < SPW; ++j) {
+                if (kok[j]) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const unsigned soff = tile_off + (unsigned)((i & 3) + 8 * (i >> 2)) * row_bytes;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[j][i] * oscale), orsrc, lane_off[j], soff, NT ? 2 : 0);
+                    }
                 }
             }
         }
@@ -229,21 +251,21 @@ bool fd_mfma_preferred(const dmx_params& prm, const WsView& ws) {
     return fd_mfma_supported(prm, ws) && M >= 24 && prm.n_selected >= 8;
 }
 
-template <bool NT, int NW>
+template <bool NT, int NW, int SPW>
 static int launch_mfma_t(const WsView& ws, const MfmaArgs& a, int64_t blocks, size_t smem, float2* out, hipStream_t stream) {
-    const void* kfn = reinterpret_cast<const void*>(k2_fd_mfma<NT, NW>);
+    const void* kfn = reinterpret_cast<const void*>(k2_fd_mfma<NT, NW, SPW>);
     if (smem > 64 * 1024) {     // per device and cheap: no cached flag, so every GPU of a process gets it
         hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MAX_ROWS * ROW_BYTES + 1024);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
     }
-    hipLaunchKernelGGL((k2_fd_mfma<NT, NW>), dim3((unsigned)blocks), dim3(NW * 64), smem, stream, ws, a, reinterpret_cast<float*>(out));
+    hipLaunchKernelGGL((k2_fd_mfma<NT, NW, SPW>), dim3((unsigned)blocks), dim3(NW * 64), smem, stream, ws, a, reinterpret_cast<float*>(out));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("k2_fd_mfma launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
     return DMX_OK;
 }
 
 int launch_channels_fd_mfma(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
-                            float2* out, bool nontemporal, int nwaves, hipStream_t stream) {
+                            float2* out, int config, hipStream_t stream) {
     MfmaArgs a;
     a.user_begin = user_begin;
     a.m_rx = prm.ue_shape[0] * prm.ue_shape[1];
@@ -260,11 +282,14 @@ int launch_channels_fd_mfma(const dmx_params& prm, const WsView& ws, int64_t use
     const size_t smem = (size_t)2 * a.rows * ROW_BYTES + LPAD * (8 + 4 + 4) + 16;
     const int64_t blocks = user_count * a.nblk;
     if (blocks > 0x7fffffffLL) { set_error("too many workgroups for one call"); return DMX_ERR_SHAPE; }
-    if (nwaves == 16) return launch_mfma_t<true, 16>(ws, a, blocks, smem, out, stream);
-    if (nwaves == 8) return nontemporal ? launch_mfma_t<true, 8>(ws, a, blocks, smem, out, stream)
-                                        : launch_mfma_t<false, 8>(ws, a, blocks, smem, out, stream);
-    return nontemporal ? launch_mfma_t<true, 4>(ws, a, blocks, smem, out, stream)
-                       : launch_mfma_t<false, 4>(ws, a, blocks, smem, out, stream);
+    switch (config) {
+        case 1: return launch_mfma_t<false, 16, 1>(ws, a, blocks, smem, out, stream);   // plain stores
+        case 2: return launch_mfma_t<true, 4, 1>(ws, a, blocks, smem, out, stream);
+        case 3: return launch_mfma_t<true, 8, 1>(ws, a, blocks, smem, out, stream);
+        case 4: return launch_mfma_t<true, 8, 2>(ws, a, blocks, smem, out, stream);
+        case 5: return launch_mfma_t<true, 16, 2>(ws, a, blocks, smem, out, stream);
+        default: return launch_mfma_t<true, 16, 1>(ws, a, blocks, smem, out, stream);
+    }
 }
 
 }  // namespace dmx
