@@ -120,21 +120,30 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; on a box with fewer GPUs than ranks (rehearsal only) ranks wrap around
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", device_id=dev)
+        # RCCL ("nccl" on ROCm) for the barrier / timing reduction; DMX_DIST_BACKEND=gloo lets two ranks
+        # rehearse the multi-rank path on a single-GPU box (RCCL refuses two ranks on one device)
+        backend = os.environ.get("DMX_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist_mod.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist_mod.init_process_group(backend=backend)
         dist = dist_mod
+    red_dev = dev if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")
 
     from deepmimo_amd.engine import ChannelEngine
     w = dict(WORKLOADS[args.workload])
     if args.users:
         w["n_ue"] = args.users
     n_ue = w["n_ue"]
-    eng = ChannelEngine(local_rank)
+    eng = ChannelEngine(dev_index)
     params = make_params(w)
     rays_t = synth_device_rays(n_ue, w["L"], 1234 + rank, dev, all_valid=not args.random_valid)
     rays = eng.upload_rays(rays_t)
@@ -166,7 +175,7 @@ def main():
     elapsed = time.perf_counter() - t0
     k2_ms = float(np.mean([a.elapsed_time(b) for a, b in evs])) if args.steps else float("nan")
     if dist:
-        t = torch.tensor([elapsed, k2_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, k2_ms], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, k2_ms = float(t[0]), float(t[1])
 

@@ -13,7 +13,7 @@ ABI_VERSION = 1
 
 EXPORTED_SYMBOLS = ("dmx_version", "dmx_last_error", "dmx_workspace_bytes", "dmx_decode_max_delay",
                     "dmx_path_prep", "dmx_channels_fd", "dmx_channels_td", "dmx_channels_fd_lpf",
-                    "dmx_lpf_workspace_bytes")
+                    "dmx_lpf_workspace_bytes", "dmx_mat5_find", "dmx_mat_to_rowmajor_f32")
 
 PATTERN_IDS = {"isotropic": 0, "halfwave-dipole": 1}
 
@@ -49,6 +49,12 @@ class DmxSide(C.Structure):
                 ("aoa_el_rot", C.c_void_p), ("aoa_az_rot", C.c_void_p),
                 ("power_linear", C.c_void_p), ("power_linear_ant_gain", C.c_void_p),
                 ("max_delay_key", C.c_void_p)]
+
+
+class DmxMatInfo(C.Structure):
+    _fields_ = [("class_id", C.c_int32), ("data_type", C.c_int32), ("elem_bytes", C.c_int32), ("ndim", C.c_int32),
+                ("dims", C.c_int64 * 4), ("data_offset", C.c_int64), ("data_bytes", C.c_int64),
+                ("compressed", C.c_int32), ("reserved", C.c_int32), ("comp_offset", C.c_int64), ("comp_bytes", C.c_int64)]
 
 
 class NativeError(RuntimeError):
@@ -89,6 +95,11 @@ def load():
     lib.dmx_channels_fd_lpf.restype = C.c_int
     lib.dmx_channels_fd_lpf.argtypes = [C.POINTER(DmxParams), C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64,
                                         C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.dmx_mat5_find.restype = C.c_int
+    lib.dmx_mat5_find.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.POINTER(DmxMatInfo)]
+    lib.dmx_mat_to_rowmajor_f32.restype = C.c_int
+    lib.dmx_mat_to_rowmajor_f32.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
+                                            C.c_int32, C.c_void_p, C.c_void_p]
     v = lib.dmx_version()
     if v != ABI_VERSION:
         raise RuntimeError(f"deepmimo_amd: ABI mismatch, library reports {v}, binding expects {ABI_VERSION}")

@@ -12,6 +12,11 @@
 selection rules of core.py:139-258, 261-338.  There is no network here, so a missing scenario is
 an error instead of a download prompt (core.py:103-109).  Scene / material objects (plot-only
 metadata) are left as the raw dictionaries.
+
+``load(..., device='cuda')`` (extension) keeps the eight per-path matrices out of
+host NumPy altogether: each file is memory-mapped, its payload copied to HBM as stored and laid out
+row-major by a device pass (deepmimo_amd/matio.py); the Dataset then holds torch tensors for those
+fields and ``compute_channels`` uses them in place.
 """
 from __future__ import annotations
 
@@ -52,7 +57,7 @@ def generate(scen_name: str, load_params: Dict[str, Any] = {}, ch_gen_params: Di
 
 
 def load(scen_name: str, **load_params):
-    """core.py:63-137 without the download prompt."""
+    """core.py:63-137 without the download prompt.  Extra keyword: device=None | 'cuda' | 'cuda:N'."""
     if os.path.isabs(scen_name):
         folder, scen_name = scen_name, os.path.basename(scen_name.rstrip(os.sep))
     else:
@@ -118,7 +123,7 @@ def _validate_txrx_sets(sets, txrx_dict: Dict[str, Any], tx_or_rx: str) -> Dict[
 
 
 def _load_raytracing_scene(folder: str, txrx_dict: dict, max_paths: int = c.MAX_PATHS, tx_sets="all",
-                           rx_sets="all", matrices="all"):
+                           rx_sets="all", matrices="all", device=None):
     tx_sets = _validate_txrx_sets(tx_sets, txrx_dict, "tx")
     rx_sets = _validate_txrx_sets(rx_sets, txrx_dict, "rx")
     out: List[Dict[str, Any]] = []
@@ -127,7 +132,7 @@ def _load_raytracing_scene(folder: str, txrx_dict: dict, max_paths: int = c.MAX_
             for tx_idx in tx_idxs:
                 print(f"Loading TXRX PAIR: TXset {tx_set_id} (tx_idx {tx_idx}) & RXset {rx_set_id} "
                       f"(rx_idxs {len(rx_idxs)})")
-                d = _load_tx_rx_raydata(folder, tx_set_id, rx_set_id, int(tx_idx), rx_idxs, max_paths, matrices)
+                d = _load_tx_rx_raydata(folder, tx_set_id, rx_set_id, int(tx_idx), rx_idxs, max_paths, matrices, device)
                 d["txrx"] = {"tx_set_id": tx_set_id, "rx_set_id": rx_set_id, "tx_idx": int(tx_idx)}
                 out.append(d)
     if len(out) > 1:
@@ -136,7 +141,7 @@ def _load_raytracing_scene(folder: str, txrx_dict: dict, max_paths: int = c.MAX_
 
 
 def _load_tx_rx_raydata(folder: str, tx_set_id: int, rx_set_id: int, tx_idx: int, rx_idxs, max_paths: int,
-                        matrices="all") -> Dict[str, Any]:
+                        matrices="all", device=None) -> Dict[str, Any]:
     """core.py:186-258"""
     import scipy.io
     if isinstance(matrices, str) and matrices == "all":
@@ -153,6 +158,10 @@ def _load_tx_rx_raydata(folder: str, tx_set_id: int, rx_set_id: int, tx_idx: int
         path = os.path.join(folder, get_mat_filename(key, tx_set_id, tx_idx, rx_set_id))
         if not os.path.exists(path):
             print(f"File {path} could not be found")
+            continue
+        if device is not None and key in c.RAY_FIELDS:
+            from .matio import load_matrix_to_device
+            d[key] = load_matrix_to_device(path, key, device, rx_idxs=rx_idxs, max_paths=max_paths)
             continue
         m = scipy.io.loadmat(path)[key]
         if key != c.TX_POS_PARAM_NAME:

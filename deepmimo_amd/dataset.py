@@ -238,7 +238,10 @@ class Dataset(DotDict):
         return np.linalg.norm(self.rx_pos - self.tx_pos, axis=1)             # dataset.py:661-663
 
     def _compute_inter_int(self) -> np.ndarray:
-        v = np.array(self.inter, copy=True)                                  # dataset.py:629-637
+        inter = self.inter
+        if hasattr(inter, "detach"):                                         # device-resident rays (load(device=...))
+            inter = inter.detach().cpu().numpy()
+        v = np.array(inter, copy=True)                                       # dataset.py:629-637
         v[np.isnan(v)] = -1
         return v.astype(int)
 

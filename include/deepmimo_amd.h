@@ -151,6 +151,34 @@ int dmx_channels_fd_lpf(const dmx_params* prm, const void* workspace, int64_t n_
 int dmx_channels_td(const dmx_params* prm, const void* workspace, int64_t n_ue, int32_t n_paths_loaded,
                     int64_t user_begin, int64_t user_count, void* out_c64, void* stream);
 
+/* ---- loader step before the path: reference .mat files -> device SoA ------------ */
+
+/* Where one numeric array lives inside a MATLAB level-5 MAT-file image, as written by scipy.io.savemat
+ * in the DeepMIMO converter (deepmimo/converter/converter_utils.py:59-85). */
+typedef struct dmx_mat_info {
+    int32_t class_id;      /* mxCLASS of the array (7 = single, 6 = double, 12 = int32, ...) */
+    int32_t data_type;     /* miTYPE of the stored payload (7 = miSINGLE, 9 = miDOUBLE, 5 = miINT32, ...) */
+    int32_t elem_bytes;
+    int32_t ndim;
+    int64_t dims[4];       /* MATLAB order; payload is column-major */
+    int64_t data_offset;   /* byte offset of the payload in the file image */
+    int64_t data_bytes;
+    int32_t compressed;    /* 1: the element is zlib-compressed (miCOMPRESSED) at [comp_offset, +comp_bytes):   */
+    int32_t reserved;      /*    inflate it and call dmx_mat5_find again on the inflated element              */
+    int64_t comp_offset;
+    int64_t comp_bytes;
+} dmx_mat_info;
+
+/* Host-side: locate variable `var_name` (NULL = first array) in a MAT-file image.  Replaces the parsing
+ * half of scipy.io.loadmat at deepmimo/generator/core.py:241.  No GPU involved. */
+int dmx_mat5_find(const void* file_image, size_t len, const char* var_name, dmx_mat_info* info);
+
+/* Device: raw column-major [rows, cols] payload (copied to HBM as stored) -> row-major float32
+ * [n_sel, cols_keep], gathering rows d_row_idx (device int64 [n_sel], NULL = the first n_sel rows) and
+ * keeping the first cols_keep columns.  Replaces core.py:250 (rx_idxs select) and :254 (max_paths trim). */
+int dmx_mat_to_rowmajor_f32(const void* d_payload, int32_t data_type, int64_t rows, int64_t cols,
+                            const int64_t* d_row_idx, int64_t n_sel, int32_t cols_keep, float* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

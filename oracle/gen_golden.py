@@ -57,6 +57,8 @@ CASES = [
     _case("g09_random_ue_rot", 24, 8, 109, [4, 2], [2, 2], 64, [0, 3, 6], ue_rot_mode="random",
           ue_rot=[[0, 30], [0, 20], [-45, 45]], ue_fov=[120, 90]),
     _case("g10_doppler_v3", 16, 8, 110, [4, 2], [2, 1], 64, list(range(64)), doppler=True, all_valid=False),
+    _case("g13_doppler_lpf_v3", 8, 6, 114, [4, 1], [2, 1], 32, list(range(0, 32, 3)), doppler=True, rx_filter=1,
+          max_delay=2.5e-6),
     _case("g11_headline_phase", 4, 25, 111, [8, 8], [2, 2], 512, list(range(512)), all_valid=True,
           max_delay=0.98 * 512 / 10e6, subsample=dict(tx=list(range(0, 64, 7)), k=list(range(0, 512, 16)) + [511])),
     _case("g12_ula64_rot", 8, 25, 112, [64, 1], [1, 4], 128, list(range(0, 128, 5)), bs_rot=[0, 0, -135],

@@ -104,10 +104,11 @@ def test_golden(name, variant, capsys):
         assert warned == bool(ref["warned"])
 
 
-def test_doppler_golden():
+@pytest.mark.parametrize("name", ["g10_doppler_v3", "g13_doppler_lpf_v3"])
+def test_doppler_golden(name):
     """Doppler term: golden from the v3 generator (the only Python definition, SURVEY finding 4)."""
     import deepmimo_amd as dm
-    case, rays, ue_rot, ref = load_golden("g10_doppler_v3")
+    case, rays, ue_rot, ref = load_golden(name)
     ds = _dataset(case, rays, with_doppler=True)
     ds["rt_params"] = {"frequency": 3.5e9}
     p = _dm_params(case, ue_rot)
@@ -235,6 +236,37 @@ def test_random_ue_rotation_matches_reference_rng_order():
     np.testing.assert_array_equal(ds["_fov_mask"], ref["fov_mask"])
 
 
+def test_generate_from_scenario_folder(tmp_path, monkeypatch):
+    """dm.generate(scen_name, load_params, ch_gen_params) (core.py:36-61): load + compute_channels, with a
+    scenario written in the reference's on-disk layout and two TX points -> MacroDataset fan-out."""
+    import json
+    import scipy.io
+    import deepmimo_amd as dm
+    from oracle import oracle_np as onp
+    folder = tmp_path / "deepmimo_scenarios" / "toy"
+    folder.mkdir(parents=True)
+    params = {"rt_params": {"frequency": 28e9}, "scene": {"num_scenes": 1}, "materials": {},
+              "txrx_sets": {"txrx_set_0": {"id": 0, "is_tx": True, "is_rx": False, "num_points": 2, "name": "bs"},
+                            "txrx_set_1": {"id": 1, "is_tx": False, "is_rx": True, "num_points": 20, "name": "ue"}}}
+    (folder / "params.json").write_text(json.dumps(params))
+    rays = [onp.synth_rays(20, 6, seed=30 + t) for t in range(2)]
+    for t in range(2):
+        for k, v in rays[t].items():
+            scipy.io.savemat(str(folder / dm.core.get_mat_filename(k, 0, t, 1)), {k: v})
+    monkeypatch.chdir(tmp_path)
+    p = dm.ChannelGenParameters()
+    p.bs_antenna.shape = np.array([4, 2])
+    p.ofdm.selected_subcarriers = np.arange(0, 512, 32)
+    md = dm.generate("toy", {"max_paths": 5}, p)
+    assert isinstance(md, dm.MacroDataset) and len(md) == 2
+    for t in range(2):
+        sub = {k: (v[:, :5] if v.ndim == 2 and k not in ("rx_pos", "tx_pos") else v) for k, v in rays[t].items()}
+        op = onp.make_params(bs_antenna=dict(shape=[4, 2]), ofdm=dict(selected_subcarriers=np.arange(0, 512, 32)))
+        ref = onp.compute_channels(sub, op)
+        assert_channel_close(md[t].channel, ref["channel"], what=f"generate tx {t}")
+        np.testing.assert_array_equal(md[t].los, ref["los"])
+
+
 def test_errors_are_loud():
     import deepmimo_amd as dm
     from deepmimo_amd._native import NativeError
@@ -253,9 +285,49 @@ def test_errors_are_loud():
     p.ofdm.bandwidth = 0.0
     with pytest.raises(NativeError):
         ds.compute_channels(p)
+    wide = dm.Dataset(dict(onp.synth_rays(4, 40, seed=9)))           # more than 32 paths: unsupported, loudly
+    p = dm.ChannelGenParameters()
+    p.num_paths = 40
+    with pytest.raises(NativeError, match="32 paths"):
+        wide.compute_channels(p)
+    p.num_paths = 25                                                   # ... but 40 loaded / 25 used is fine
+    assert wide.compute_channels(p).shape == (4, 1, 8, 1)
+    assert wide.num_paths.max() <= 40
     dm.config("use_gpu", False)
     try:
         with pytest.raises(RuntimeError):
             dm.Dataset(dict(rays)).compute_channels()
     finally:
         dm.config("use_gpu", True)
+
+
+def test_device_loader_matches_scipy(tmp_path):
+    """load(..., device='cuda'): .mat payload -> HBM -> row-major float32 by the device pass, equal to the
+    reference's scipy.io.loadmat + slicing (core.py:241-254), then channels from the device-resident rays."""
+    import json
+    import scipy.io
+    import torch
+    import deepmimo_amd as dm
+    from oracle import oracle_np as onp
+    rays = onp.synth_rays(333, 25, seed=21)
+    folder = tmp_path / "scen"
+    folder.mkdir()
+    params = {"rt_params": {"frequency": 3.5e9}, "scene": {"num_scenes": 1}, "materials": {},
+              "txrx_sets": {"txrx_set_0": {"id": 0, "is_tx": True, "is_rx": False, "num_points": 1, "name": "bs"},
+                            "txrx_set_1": {"id": 1, "is_tx": False, "is_rx": True, "num_points": 333, "name": "ue"}}}
+    (folder / "params.json").write_text(json.dumps(params))
+    for k, v in rays.items():
+        vv = v.astype(np.float64) if k == "delay" else v                       # one file in another dtype
+        scipy.io.savemat(str(folder / dm.core.get_mat_filename(k, 0, 0, 1)), {k: vv}, do_compression=(k == "phase"))
+    sel = np.arange(332, -1, -3)
+    host = dm.load(str(folder), max_paths=10, rx_sets={1: sel})
+    devd = dm.load(str(folder), max_paths=10, rx_sets={1: sel}, device="cuda")
+    for k in dm.consts.RAY_FIELDS:
+        assert isinstance(devd[k], torch.Tensor) and devd[k].is_cuda and devd[k].dtype == torch.float32
+        np.testing.assert_array_equal(devd[k].cpu().numpy(), host[k].astype(np.float32))
+    np.testing.assert_array_equal(devd.rx_pos, host.rx_pos)
+    p = dm.ChannelGenParameters()
+    p.bs_antenna.shape = np.array([8, 4])
+    Hd, Hh = devd.compute_channels(p), host.compute_channels(p)
+    assert np.array_equal(Hd, Hh)
+    np.testing.assert_array_equal(devd.los, host.los)

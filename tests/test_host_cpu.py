@@ -172,3 +172,30 @@ def test_loader_reads_reference_layout(tmp_path):
         dm.load(str(tmp_path / "missing"))
     with pytest.raises(Exception):
         dm.load(str(folder), tx_sets=[5])
+
+
+def test_mat5_parser_finds_payload(tmp_path):
+    """dmx_mat5_find (host-only) on files written exactly like the reference's converter writes them
+    (scipy.io.savemat, converter_utils.py:85): dims, dtype and payload offset for plain and compressed files."""
+    import ctypes as C
+    import scipy.io
+    from deepmimo_amd import _native as n
+    from deepmimo_amd.matio import find_array
+    rng = np.random.default_rng(3)
+    a = rng.uniform(-1, 1, (37, 25)).astype(np.float32)
+    a[5, 20:] = np.nan
+    for name, arr, comp in (("power", a, False), ("power", a, True), ("inter", np.arange(12, dtype=np.int32).reshape(4, 3), False),
+                            ("delay", a.astype(np.float64), False)):
+        path = tmp_path / f"{name}_{int(comp)}_{arr.dtype}.mat"
+        scipy.io.savemat(str(path), {name: arr}, do_compression=comp)
+        raw = path.read_bytes()
+        info, image = find_array(raw, name)
+        assert info.ndim == 2 and (info.dims[0], info.dims[1]) == arr.shape
+        assert info.elem_bytes == arr.dtype.itemsize and info.data_bytes == arr.nbytes
+        payload = np.frombuffer(image, dtype=arr.dtype, count=arr.size, offset=info.data_offset)
+        np.testing.assert_array_equal(payload.reshape(arr.shape[::-1]).T, arr)      # column-major on disk
+    lib = n.load()
+    info = n.DmxMatInfo()
+    assert lib.dmx_mat5_find(C.c_char_p(raw), len(raw), b"nope", C.byref(info)) != 0
+    assert b"not found" in lib.dmx_last_error()
+    assert lib.dmx_mat5_find(C.c_char_p(b"x" * 200), 200, None, C.byref(info)) != 0

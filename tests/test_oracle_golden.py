@@ -54,9 +54,11 @@ def test_reference_style_loop_equals_batched(name):
     assert_channel_close(res_r["channel"], res_b["channel"], tol_rel=1e-7, what=name)
 
 
-def test_doppler_term_matches_v3():
-    """v4 has no Doppler implementation; the v3 generator's term is the oracle (SURVEY finding 4)."""
-    case, rays, ue_rot, ref = load_golden("g10_doppler_v3")
+@pytest.mark.parametrize("name", ["g10_doppler_v3", "g13_doppler_lpf_v3"])
+def test_doppler_term_matches_v3(name):
+    """v4 has no Doppler implementation; the v3 generator's term is the oracle (SURVEY finding 4).
+    g13 is the rx_filter branch, where the Doppler phase depends on the tap delay Ts*d."""
+    case, rays, ue_rot, ref = load_golden(name)
     params = oracle_params(case, ue_rot)
     params["enable_doppler"] = 1
     dop = dict(vel=rays["doppler_vel"], acc=rays["doppler_acc"], carrier_freq=3.5e9)

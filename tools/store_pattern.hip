@@ -57,6 +57,50 @@ __global__ __launch_bounds__(1024) void pattern(float* __restrict__ out, float v
     }
 }
 
+// mode 4: like mode 2 (1 KiB per store instruction, 1 MiB block per workgroup) with plain stores
+// mode 5: like torch fill_: 256-thread workgroups, consecutive workgroups write consecutive 16 KiB chunks
+// mode 6: mode 0 with plain stores
+// mode 7: mode 5 with nt stores
+template <int AUX>
+__global__ __launch_bounds__(1024) void pattern_rows(float* __restrict__ out, float v) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* o = out + (size_t)blockIdx.x * 256 * 1024;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(o, 0, 256 * 1024 * 4, 0x00020000);
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const u4 d = {__builtin_bit_cast(unsigned, v), 1u, 2u, 3u};
+    for (int r = wave * 16; r < wave * 16 + 16; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_raw_buffer_store_b128(d, rs, (unsigned)(q * 256 + lane * 4) * 4u, (unsigned)r * 4096u, AUX);
+}
+
+template <bool NT>
+__global__ __launch_bounds__(256) void pattern_linear(float4* __restrict__ out4, float v) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4* o = reinterpret_cast<f4*>(out4) + (size_t)blockIdx.x * 1024 + threadIdx.x;       // 16 KiB per workgroup
+    const f4 d = {v, 1.f, 2.f, 3.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (NT) __builtin_nontemporal_store(d, o + i * 256); else o[i * 256] = d;
+    }
+}
+
+template <int AUX>
+__global__ __launch_bounds__(1024) void pattern_tiles(float* __restrict__ out, float v) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* o = out + (size_t)blockIdx.x * 256 * 1024;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(o, 0, 256 * 1024 * 4, 0x00020000);
+    const int col = lane & 31, hh = lane >> 5;
+    for (int strip = wave; strip < 32; strip += 16) {
+        const unsigned lane_off = ((unsigned)(4 * hh) * 1024u + (unsigned)(strip * 32 + col)) * 4u;
+        for (int pt = 0; pt < 8; ++pt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + i), rs, lane_off,
+                                                      (unsigned)(pt * 32 + (i & 3) + 8 * (i >> 2)) * 4096u, AUX);
+    }
+}
+
 int main() {
     const int users = 100000;
     float* out;
@@ -64,7 +108,7 @@ int main() {
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
     const double gb = (double)users * 256 * 1024 * 4 / 1e9;
-    for (int mode = 0; mode < 4; ++mode) {
+    for (int mode = 0; mode < 8; ++mode) {
         float best = 1e9f;
         for (int rep = 0; rep < 4; ++rep) {
             hipEventRecord(a);
@@ -72,6 +116,10 @@ int main() {
             if (mode == 1) pattern<1><<<users, 1024>>>(out, 1.f);
             if (mode == 2) pattern<2><<<users, 1024>>>(out, 1.f);
             if (mode == 3) pattern<3><<<users, 1024>>>(out, 1.f);
+            if (mode == 4) pattern_rows<0><<<users, 1024>>>(out, 1.f);
+            if (mode == 5) pattern_linear<false><<<users * 64, 256>>>((float4*)out, 1.f);
+            if (mode == 6) pattern_tiles<0><<<users, 1024>>>(out, 1.f);
+            if (mode == 7) pattern_linear<true><<<users * 64, 256>>>((float4*)out, 1.f);
             hipEventRecord(b);
             hipEventSynchronize(b);
             float ms; hipEventElapsedTime(&ms, a, b);
