@@ -135,6 +135,30 @@ int dmx_channels_fd_lpf(const dmx_params* prm, const void* workspace, int64_t n_
     return launch_channels_fd_lpf(*prm, ws, user_begin, user_count, (float2*)lpf_workspace, (float2*)out_c64, (hipStream_t)stream);
 }
 
+size_t dmx_beam_workspace_bytes(const dmx_params* prm, int64_t user_count, int32_t n_paths_loaded, int32_t n_beams) {
+    if (!prm || user_count < 0 || n_paths_loaded < 0 || n_beams < 0) return 0;
+    return beam_workspace_bytes(user_count, n_beams, used_paths(prm, n_paths_loaded));
+}
+
+int dmx_channels_fd_beams(const dmx_params* prm, const void* workspace, int64_t n_ue, int32_t n_paths_loaded,
+                          int64_t user_begin, int64_t user_count, const void* codebook_c64, int32_t n_beams,
+                          void* beam_workspace, size_t beam_workspace_bytes_, void* out_c64, void* stream) {
+    WsView ws;
+    int rc = stage2_common(prm, workspace, n_ue, n_paths_loaded, user_begin, user_count, out_c64, &ws);
+    if (rc) return rc;
+    if (!prm->freq_domain || prm->rx_filter) { set_error("dmx_channels_fd_beams needs freq_domain = 1 and rx_filter = 0"); return DMX_ERR_ARG; }
+    if (n_beams < 0 || (n_beams > 0 && !codebook_c64)) { set_error("codebook missing"); return DMX_ERR_ARG; }
+    if (prm->n_selected == 0 || n_beams == 0) return DMX_OK;
+    if (!fd_mfma_supported(*prm, ws)) { set_error("num_paths = %d exceeds the 32 paths the beam-space kernel supports", ws.P); return DMX_ERR_SHAPE; }
+    const size_t need = beam_workspace_bytes(user_count, n_beams, ws.P);
+    if (!beam_workspace || beam_workspace_bytes_ < need || ((uintptr_t)beam_workspace & 255u)) {
+        set_error("beam workspace too small or misaligned: need %zu bytes, 256-byte aligned", need);
+        return DMX_ERR_WORKSPACE;
+    }
+    return launch_channels_fd_beams(*prm, ws, user_begin, user_count, (const float2*)codebook_c64, n_beams, beam_workspace,
+                                    (float2*)out_c64, (hipStream_t)stream);
+}
+
 int dmx_channels_td(const dmx_params* prm, const void* workspace, int64_t n_ue, int32_t n_paths_loaded,
                     int64_t user_begin, int64_t user_count, void* out_c64, void* stream) {
     WsView ws;

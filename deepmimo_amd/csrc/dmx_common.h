@@ -75,6 +75,10 @@ int launch_channels_fd(const dmx_params& prm, const WsView& ws, int64_t user_beg
                        float2* out, int variant, hipStream_t stream);
 int launch_channels_fd_lpf(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
                            float2* gtab, float2* out, hipStream_t stream);
+int launch_channels_fd_beams(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
+                             const float2* codebook, int n_beams, void* beam_ws, float2* out, hipStream_t stream);
+size_t beam_workspace_bytes(int64_t user_count, int n_beams, int P);
+bool fd_mfma_supported(const dmx_params& prm, const WsView& ws);
 int launch_channels_td(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
                        float2* out, hipStream_t stream);
 

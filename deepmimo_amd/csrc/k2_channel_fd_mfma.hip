@@ -50,6 +50,10 @@ struct MfmaArgs {
     double inv_n;
     int nblk;        // row blocks per user
     int rows;        // LDS rows (multiple of 32)
+    // fused TX-codebook projection (k2b_beam_project): rows are (rx, beam) instead of (rx, tx)
+    int n_beams;             // 0 = plain channel
+    const float2* ftab;      // [user_count, n_beams, P]  f[b,l] = sum_tx F[b,tx] a_tx[tx,l]
+    const int32_t* fexp;     // [user_count]              exponent of max |f| per user
 };
 
 // (x0, x1) -> packed hi pair and packed lo pair, x = hi + lo.  v_cvt_pkrtz_f16_f32 converts two floats per
@@ -154,7 +158,10 @@ __global__ __launch_bounds__(NW * 64) void k2_fd_mfma(WsView ws, MfmaArgs a, flo
             crtab[lane] = ok ? ws.c_re[rb + lane] * gs : 0.f;
             citab[lane] = ok ? ws.c_im[rb + lane] * gs : 0.f;
         }
-        if (lane == 0) misc[0] = ldexpf(1.0f, e - 10 - 6);              // 1 / (gs * A_SCALE)
+        // A' scale: 64 for unit-modulus array responses; with a codebook the projected responses f are
+        // scaled per user so that max |f| lands in [32, 64)
+        const int ea = a.n_beams ? 6 - a.fexp[ul] : 6;
+        if (lane == 0) { misc[0] = ldexpf(1.0f, e - 10 - ea); misc[1] = ldexpf(1.0f, ea); }   // 1 / (gs * A scale)
     }
 
     // phase 1: A' tiles.  thread = (row = antenna pair, slice of the path slots)
@@ -164,21 +171,39 @@ __global__ __launch_bounds__(NW * 64) void k2_fd_mfma(WsView ws, MfmaArgs a, flo
         if (r < a.rows) {
             const int p = row0 + r;
             const bool pok = p < a.M;
-            const int rx = pok ? p / a.m_tx : 0, tx = pok ? p - rx * a.m_tx : 0;
+            const int ncolA = a.n_beams ? a.n_beams : a.m_tx;              // second index of the row pair
+            const int rx = pok ? p / ncolA : 0, tx = pok ? p - rx * ncolA : 0;
             const double yr = (double)(rx % a.ue_mh), zr = (double)(rx / a.ue_mh);
             const double yt = (double)(tx % a.bs_mh), zt = (double)(tx / a.bs_mh);
             h2* rhi = reinterpret_cast<h2*>(Ahi + (size_t)r * ROW_BYTES);
             h2* rlo = reinterpret_cast<h2*>(Alo + (size_t)r * ROW_BYTES);
-            for (int l = l0; l < l0 + LPER; ++l) {
-                h2 vh = {(_Float16)0.f, (_Float16)0.f}, vl = vh;
-                if (pok && l < n_act) {
-                    const double ph = yr * ws.rx_y[rb + l] + zr * ws.rx_z[rb + l] + yt * ws.tx_y[rb + l] + zt * ws.tx_z[rb + l];
-                    float s, c;
-                    sincos_rev(frac_rev(ph), s, c);
-                    split2_f16(c * A_SCALE, s * A_SCALE, vh, vl);
+            if (a.n_beams) {
+                // beam-space rows: A[(rx,b), l] = a_rx[rx,l] * f[b,l]  (f from k2b_beam_project)
+                const float2* frow = a.ftab + ((size_t)ul * a.n_beams + tx) * ws.P;
+                const float ascale = ldexpf(1.0f, 6 - a.fexp[ul]);
+                for (int l = l0; l < l0 + LPER; ++l) {
+                    h2 vh = {(_Float16)0.f, (_Float16)0.f}, vl = vh;
+                    if (pok && l < n_act) {
+                        float s, c;
+                        sincos_rev(frac_rev(yr * ws.rx_y[rb + l] + zr * ws.rx_z[rb + l]), s, c);
+                        const float2 f = frow[l];
+                        split2_f16((c * f.x - s * f.y) * ascale, (c * f.y + s * f.x) * ascale, vh, vl);
+                    }
+                    rhi[l] = vh;
+                    rlo[l] = vl;
                 }
-                rhi[l] = vh;
-                rlo[l] = vl;
+            } else {
+                for (int l = l0; l < l0 + LPER; ++l) {
+                    h2 vh = {(_Float16)0.f, (_Float16)0.f}, vl = vh;
+                    if (pok && l < n_act) {
+                        const double ph = yr * ws.rx_y[rb + l] + zr * ws.rx_z[rb + l] + yt * ws.tx_y[rb + l] + zt * ws.tx_z[rb + l];
+                        float s, c;
+                        sincos_rev(frac_rev(ph), s, c);
+                        split2_f16(c * A_SCALE, s * A_SCALE, vh, vl);
+                    }
+                    rhi[l] = vh;
+                    rlo[l] = vl;
+                }
             }
         }
     }
@@ -241,6 +266,66 @@ __global__ __launch_bounds__(NW * 64) void k2_fd_mfma(WsView ws, MfmaArgs a, flo
     }
 }
 
+// Fused consumer of H (docs/manual.ipynb cell 105: `F1 @ dataset.channel`): for a TX
+// codebook F [B, M_tx] the beam-space channel Y[u,rx,b,k] = sum_tx F[b,tx] H[u,rx,tx,k] is the SAME
+// contraction with the transmit array response replaced by its projection f[b,l] = sum_tx F[b,tx] a_tx[tx,l].
+// This kernel builds f per user (a_tx table in LDS, B*L*M_tx complex MACs: ~3 % of the contraction) and the
+// power-of-two exponent of max|f| that k2_fd_mfma uses to scale its f16 operands.  The [N,M_rx,M_tx,K]
+// tensor is never written: output (and HBM traffic) shrinks by M_tx / B.
+struct BeamArgs {
+    int64_t user_begin;
+    int m_tx, bs_mh, n_beams;
+    const float2* F;         // [n_beams, m_tx] complex64, row-major
+    float2* ftab;            // [user_count, n_beams, P]
+    int32_t* fexp;           // [user_count]
+};
+
+__global__ __launch_bounds__(256) void k2b_beam_project(WsView ws, BeamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2* atx = reinterpret_cast<float2*>(smem);                       // [m_tx][P]
+    __shared__ float wmax[4];
+    const int tid = threadIdx.x;
+    const int64_t ul = blockIdx.x, u = a.user_begin + ul;
+    const int P = ws.P;
+    int n_act = ws.n_keep[u];
+    n_act = n_act < LPAD ? n_act : LPAD;
+    const size_t rb = (size_t)u * P;
+    for (int i = tid; i < a.m_tx * P; i += 256) {
+        const int t = i / P, l = i - t * P;
+        float s = 0.f, c = 0.f;
+        if (l < n_act) {
+            const int y = t % a.bs_mh, z = t / a.bs_mh;
+            sincos_rev(frac_rev((double)y * ws.tx_y[rb + l] + (double)z * ws.tx_z[rb + l]), s, c);
+        }
+        atx[i] = make_float2(c, s);
+    }
+    __syncthreads();
+    float m = 0.f;
+    for (int i = tid; i < a.n_beams * P; i += 256) {
+        const int b = i / P, l = i - b * P;
+        float fr = 0.f, fi = 0.f;
+        if (l < n_act) {
+            const float2* Frow = a.F + (size_t)b * a.m_tx;
+            for (int t = 0; t < a.m_tx; ++t) {
+                const float2 w = Frow[t], v = atx[t * P + l];
+                fr = fmaf(w.x, v.x, fr); fr = fmaf(-w.y, v.y, fr);
+                fi = fmaf(w.x, v.y, fi); fi = fmaf(w.y, v.x, fi);
+            }
+        }
+        a.ftab[((size_t)ul * a.n_beams + b) * P + l] = make_float2(fr, fi);
+        m = fmaxf(m, fmaxf(fabsf(fr), fabsf(fi)));
+    }
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((tid & 63) == 0) wmax[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+        m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        int e = 0;
+        if (m > 0.f) (void)frexpf(m, &e);
+        a.fexp[ul] = e;
+    }
+}
+
 bool fd_mfma_supported(const dmx_params& prm, const WsView& ws) {
     return ws.P <= LPAD && prm.n_selected >= 1 && !prm.rx_filter;
 }
@@ -264,15 +349,48 @@ static int launch_mfma_t(const WsView& ws, const MfmaArgs& a, int64_t blocks, si
     return DMX_OK;
 }
 
+static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
+                           float2* out, int config, int n_beams, const float2* ftab, const int32_t* fexp, hipStream_t stream);
+
 int launch_channels_fd_mfma(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
                             float2* out, int config, hipStream_t stream) {
+    return launch_mfma_any(prm, ws, user_begin, user_count, out, config, 0, nullptr, nullptr, stream);
+}
+
+size_t beam_workspace_bytes(int64_t user_count, int n_beams, int P) {
+    return align_up((size_t)user_count * (size_t)n_beams * (size_t)P * 8, 256) + align_up((size_t)user_count * 4, 256);
+}
+
+int launch_channels_fd_beams(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
+                             const float2* codebook, int n_beams, void* beam_ws, float2* out, hipStream_t stream) {
+    if (user_count == 0 || prm.n_selected == 0 || n_beams == 0) return DMX_OK;
+    BeamArgs b;
+    b.user_begin = user_begin;
+    b.m_tx = prm.bs_shape[0] * prm.bs_shape[1];
+    b.bs_mh = prm.bs_shape[0];
+    b.n_beams = n_beams;
+    b.F = codebook;
+    b.ftab = reinterpret_cast<float2*>(beam_ws);
+    b.fexp = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(beam_ws) +
+                                        align_up((size_t)user_count * (size_t)n_beams * (size_t)ws.P * 8, 256));
+    const size_t smem = (size_t)b.m_tx * (ws.P > 0 ? ws.P : 1) * 8;
+    if (smem > 64 * 1024) { set_error("BS panel of %d elements x %d paths does not fit the beam-projection table", b.m_tx, ws.P); return DMX_ERR_SHAPE; }
+    hipLaunchKernelGGL(k2b_beam_project, dim3((unsigned)user_count), dim3(256), smem, stream, ws, b);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("k2b_beam_project launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
+    return launch_mfma_any(prm, ws, user_begin, user_count, out, 0, n_beams, b.ftab, b.fexp, stream);
+}
+
+static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
+                           float2* out, int config, int n_beams, const float2* ftab, const int32_t* fexp, hipStream_t stream) {
     MfmaArgs a;
+    a.n_beams = n_beams; a.ftab = ftab; a.fexp = fexp;
     a.user_begin = user_begin;
     a.m_rx = prm.ue_shape[0] * prm.ue_shape[1];
     a.m_tx = prm.bs_shape[0] * prm.bs_shape[1];
     a.ue_mh = prm.ue_shape[0];
     a.bs_mh = prm.bs_shape[0];
-    a.M = a.m_rx * a.m_tx;
+    a.M = a.m_rx * (n_beams ? n_beams : a.m_tx);
     a.K = prm.n_selected;
     a.sc = prm.selected_subcarriers;
     a.inv_n = 1.0 / (double)prm.n_subcarriers;

@@ -179,6 +179,18 @@ class Dataset(DotDict):
         self[c.CHANNEL_PARAM_NAME] = out
         return out
 
+    def compute_beam_channels(self, codebook, params: Optional[ChannelGenParameters] = None):
+        """Beam-space channels ``codebook @ H`` for a TX codebook [n_beams, M_tx] (rows e.g. from
+        ``dm.steering_vec``), complex64 [n_ue, M_rx, n_beams, K] - what docs/manual.ipynb cell 105 computes
+        as ``F1 @ dataset.channel`` - without materialising H (extension).  Not cached."""
+        if params is None:
+            params = ChannelGenParameters() if self._data.get(c.CH_PARAMS_PARAM_NAME) is None else self.ch_params
+        self.set_channel_params(params)
+        np.random.seed(1001)
+        eng, prep = self._run_prep(want_side=True)
+        y = eng.channels(prep, tx_codebook=codebook)
+        return y if config.get("channel_output", "numpy") == "torch" else y.cpu().numpy()
+
     @staticmethod
     def _warn_symbol_duration(max_delay: float, ofdm) -> None:
         """The reference's clipping warning (channel.py:228-250), fed by the device-side max."""

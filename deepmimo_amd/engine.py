@@ -202,12 +202,25 @@ class ChannelEngine:
         return (n, m_rx, m_tx, last)
 
     def channels(self, prep: PrepResult, out: Optional[torch.Tensor] = None, user_begin: int = 0,
-                 user_count: Optional[int] = None, variant: int = 0) -> torch.Tensor:
-        """Run stage 2 for users [user_begin, user_begin + user_count) into `out` (allocated if None)."""
+                 user_count: Optional[int] = None, variant: int = 0, tx_codebook=None) -> torch.Tensor:
+        """Run stage 2 for users [user_begin, user_begin + user_count) into `out` (allocated if None).
+
+        tx_codebook: optional complex [n_beams, M_tx] beamforming matrix F; the result is then the
+        beam-space channel F @ H, complex64 [user_count, M_rx, n_beams, K], produced without ever writing H
+        (dmx_channels_fd_beams; frequency domain without rx_filter only)."""
         p = prep.params_struct
         if user_count is None:
             user_count = prep.n_ue - user_begin
         shape = self.channel_shape(prep, user_count)
+        cb = None
+        if tx_codebook is not None:
+            cb = tx_codebook if isinstance(tx_codebook, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(tx_codebook))
+            cb = cb.to(device=self.device, dtype=torch.complex64).contiguous()
+            if cb.dim() != 2 or cb.shape[1] != shape[2]:
+                raise ValueError(f"tx_codebook must be [n_beams, {shape[2]}], got {tuple(cb.shape)}")
+            if not p.freq_domain or p.rx_filter:
+                raise ValueError("tx_codebook needs freq_domain = 1 and rx_filter = 0")
+            shape = (shape[0], shape[1], int(cb.shape[0]), shape[3])
         if out is None:
             out = torch.empty(shape, dtype=torch.complex64, device=self.device)
         else:
@@ -217,7 +230,18 @@ class ChannelEngine:
             return out
         wsp = C.c_void_p(prep.workspace.data_ptr())
         with torch.cuda.device(self.device):
-            if p.freq_domain and p.rx_filter:
+            if cb is not None:
+                nb = int(cb.shape[0])
+                nbytes = int(self.lib.dmx_beam_workspace_bytes(C.byref(p), user_count, prep.n_paths_loaded, nb))
+                bws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+                off = (-bws.data_ptr()) % 256
+                rc = self.lib.dmx_channels_fd_beams(C.byref(p), wsp, prep.n_ue, prep.n_paths_loaded, user_begin,
+                                                    user_count, C.c_void_p(cb.data_ptr()), nb,
+                                                    C.c_void_p(bws.data_ptr() + off), nbytes,
+                                                    C.c_void_p(out.data_ptr()), self._stream_ptr())
+                nat.check(rc, "dmx_channels_fd_beams")
+                prep.keepalive.extend([bws, cb])
+            elif p.freq_domain and p.rx_filter:
                 nbytes = int(self.lib.dmx_lpf_workspace_bytes(C.byref(p), user_count, prep.n_paths_loaded))
                 lws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
                 off = (-lws.data_ptr()) % 256

@@ -144,6 +144,18 @@ int dmx_channels_fd_lpf(const dmx_params* prm, const void* workspace, int64_t n_
                         void* out_c64, void* stream);
 
 /*
+ * Stage 2 with a fused consumer: beam-space channel for a TX codebook F [n_beams, M_tx]
+ * (complex64, row-major, device), out[u, rx, b, k] = sum_tx F[b,tx] H[u, rx, tx, k]  - what
+ * docs/manual.ipynb cell 105 computes as `F1 @ dataset.channel` after materialising H.  H itself is never
+ * written: the projection is folded into the transmit array response before the contraction, so the output
+ * (complex64 [user_count, M_rx, n_beams, K]) and the HBM traffic shrink by M_tx / n_beams.
+ */
+size_t dmx_beam_workspace_bytes(const dmx_params* prm, int64_t user_count, int32_t n_paths_loaded, int32_t n_beams);
+int dmx_channels_fd_beams(const dmx_params* prm, const void* workspace, int64_t n_ue, int32_t n_paths_loaded,
+                          int64_t user_begin, int64_t user_count, const void* codebook_c64, int32_t n_beams,
+                          void* beam_workspace, size_t beam_workspace_bytes, void* out_c64, void* stream);
+
+/*
  * Stage 2, time domain (replaces channel.py:285-287): out[u, rx, tx, s] = a_rx a_tx sqrt(p) e^{j phase}
  * of the s-th valid path (valid paths compacted to the front, remaining slots zero),
  * complex64 [user_count, M_rx, M_tx, P], P = min(num_paths, n_paths_loaded).

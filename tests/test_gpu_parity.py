@@ -331,3 +331,35 @@ def test_device_loader_matches_scipy(tmp_path):
     Hd, Hh = devd.compute_channels(p), host.compute_channels(p)
     assert np.array_equal(Hd, Hh)
     np.testing.assert_array_equal(devd.los, host.los)
+
+
+@pytest.mark.parametrize("cfg", [dict(bs=[32, 1], ue=[1, 1], nb=16, L=9, rot=[0, 0, -135]),
+                                 dict(bs=[8, 8], ue=[2, 2], nb=64, L=25, rot=[0, 0, 0]),
+                                 dict(bs=[4, 2], ue=[3, 1], nb=5, L=4, rot=[10, 20, 30])])
+def test_beam_codebook_projection(cfg):
+    """Fused consumer: Dataset.compute_beam_channels(F) == F @ compute_channels() (docs/manual.ipynb cell 105),
+    for a steering-vector codebook and for an arbitrary un-normalised complex one."""
+    import deepmimo_amd as dm
+    from oracle import oracle_np as onp
+    rays = onp.synth_rays(70, cfg["L"], seed=55)
+    p = dm.ChannelGenParameters()
+    p.bs_antenna.shape = np.array(cfg["bs"])
+    p.ue_antenna.shape = np.array(cfg["ue"])
+    p.bs_antenna.rotation = np.array(cfg["rot"])
+    p.ofdm.selected_subcarriers = np.arange(0, 512, 7)
+    op = onp.make_params(bs_antenna=dict(shape=cfg["bs"], rotation=np.array(cfg["rot"])), ue_antenna=dict(shape=cfg["ue"]),
+                         ofdm=dict(selected_subcarriers=np.arange(0, 512, 7)))
+    Href = onp.compute_channels(rays, op)["channel"].astype(np.complex128)
+    m_tx = cfg["bs"][0] * cfg["bs"][1]
+    beams = np.around(np.linspace(-60, 60, cfg["nb"]), 2)
+    F1 = np.array([dm.steering_vec(np.array(cfg["bs"]), phi=azi).squeeze() for azi in beams])
+    rng = np.random.default_rng(1)
+    F2 = (rng.normal(size=(cfg["nb"], m_tx)) + 1j * rng.normal(size=(cfg["nb"], m_tx))) * 37.5
+    ds = dm.Dataset(dict(rays))
+    for F in (F1, F2):
+        Y = ds.compute_beam_channels(F, p)
+        Yref = (F @ Href).astype(np.complex64)                      # [n_ue, M_rx, n_beams, K]
+        assert Y.shape == Yref.shape == (70, cfg["ue"][0] * cfg["ue"][1], cfg["nb"], 74)
+        assert_channel_close(Y, Yref, what="beam-space channel")
+    with pytest.raises(ValueError):
+        ds.compute_beam_channels(np.ones((4, m_tx + 1)), p)
