@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--workload", default="c3_headline")
     ap.add_argument("--users", type=int, default=0)
     ap.add_argument("--random-valid", action="store_true")
+    ap.add_argument("--beams", type=int, default=0, help="also time the fused beam-space kernel with this many beams")
     args = ap.parse_args()
     w = dict(bench.WORKLOADS[args.workload])
     if args.users:
@@ -50,6 +51,20 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             times[v].append(e0.elapsed_time(e1))
+    if args.beams:
+        import deepmimo_amd as dm
+        F = np.array([dm.steering_vec(np.array(w["bs"]), phi=a).squeeze() for a in np.linspace(-60, 60, args.beams)])
+        outb = torch.empty((w["n_ue"], m_rx, args.beams, w["N"]), dtype=torch.complex64, device=dev)
+        eng.channels(prep, out=outb, tx_codebook=F)
+        torch.cuda.synchronize()
+        tb = []
+        for _ in range(args.rounds):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); eng.channels(prep, out=outb, tx_codebook=F); e1.record(); torch.cuda.synchronize()
+            tb.append(e0.elapsed_time(e1))
+        bb = w["n_ue"] * 8 * m_rx * args.beams * w["N"]
+        print(f"beam-space ({args.beams} beams): median {np.median(tb):.3f} ms -> {bb/np.median(tb)/1e6:.0f} GB/s of output, "
+              f"{w['n_ue']/np.median(tb)*1e3/1e6:.2f} M users/s (vs materialise H then project: H alone is {m_tx/args.beams:.0f}x the bytes)")
     bytes_ = w["n_ue"] * (8 * m_rx * m_tx * w["N"] + 32 * w["L"])
     print(f"workload {args.workload} users {w['n_ue']}  stage-1 prep median {np.median(t1):.3f} ms")
     for v in args.variants:
