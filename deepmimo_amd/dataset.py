@@ -191,6 +191,13 @@ class Dataset(DotDict):
         y = eng.channels(prep, tx_codebook=codebook)
         return y if config.get("channel_output", "numpy") == "torch" else y.cpu().numpy()
 
+    def compute_pathloss(self, coherent: bool = True) -> np.ndarray:
+        """Path loss in dB assuming 0 dBm transmitted power (dataset.py:541-566); cached as ``pathloss``."""
+        eng = _engine()
+        pl = eng.pathloss(eng.upload_rays(self), coherent).cpu().numpy()
+        self[c.PATHLOSS_PARAM_NAME] = pl
+        return pl
+
     @staticmethod
     def _warn_symbol_duration(max_delay: float, ofdm) -> None:
         """The reference's clipping warning (channel.py:228-250), fed by the device-side max."""
@@ -296,6 +303,7 @@ class Dataset(DotDict):
         c.N_UE_PARAM_NAME: "_compute_n_ue",
         c.NUM_PATHS_PARAM_NAME: "_compute_num_paths",
         c.DIST_PARAM_NAME: "_compute_distances",
+        c.PATHLOSS_PARAM_NAME: "compute_pathloss",
         c.CHANNEL_PARAM_NAME: "compute_channels",
         c.LOS_PARAM_NAME: "_compute_los",
         c.CH_PARAMS_PARAM_NAME: "set_channel_params",

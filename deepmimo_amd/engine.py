@@ -260,6 +260,18 @@ class ChannelEngine:
                 nat.check(rc, "dmx_channels_td")
         return out
 
+    def pathloss(self, rays: DeviceRays, coherent: bool = True) -> torch.Tensor:
+        """dmx_pathloss: float32 [n_ue] dB (dataset.py:541-566)."""
+        out = torch.empty((rays.n_ue,), dtype=torch.float32, device=self.device)
+        r = nat.DmxRays()
+        r.n_ue, r.n_paths, r.ld = rays.n_ue, rays.n_paths, rays.n_paths
+        if rays.n_ue * rays.n_paths > 0:
+            r.power, r.phase = rays.fields[c.POWER_PARAM_NAME].data_ptr(), rays.fields[c.PHASE_PARAM_NAME].data_ptr()
+        with torch.cuda.device(self.device):
+            rc = self.lib.dmx_pathloss(C.byref(r), int(bool(coherent)), C.c_void_p(out.data_ptr()), self._stream_ptr())
+        nat.check(rc, "dmx_pathloss")
+        return out
+
     def max_delay(self, prep: PrepResult) -> float:
         """nanmax(delay[:, :P]) as the kernel saw it (channel.py:231); synchronises."""
         key = int(prep.side["max_delay_key"].cpu().numpy().astype(np.uint32)[0])

@@ -163,6 +163,12 @@ int dmx_channels_fd_beams(const dmx_params* prm, const void* workspace, int64_t 
 int dmx_channels_td(const dmx_params* prm, const void* workspace, int64_t n_ue, int32_t n_paths_loaded,
                     int64_t user_begin, int64_t user_count, void* out_c64, void* stream);
 
+/*
+ * Consumer of the ray records: Dataset.compute_pathloss (dataset.py:541-566).  out: device float32 [n_ue], dB;
+ * coherent != 0 sums complex gains, 0 sums amplitudes; NaN where the summed power is not positive.
+ */
+int dmx_pathloss(const dmx_rays* rays, int32_t coherent, float* out, void* stream);
+
 /* ---- loader step before the path: reference .mat files -> device SoA ------------ */
 
 /* Where one numeric array lives inside a MATLAB level-5 MAT-file image, as written by scipy.io.savemat

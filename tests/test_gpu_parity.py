@@ -363,3 +363,25 @@ def test_beam_codebook_projection(cfg):
         assert_channel_close(Y, Yref, what="beam-space channel")
     with pytest.raises(ValueError):
         ds.compute_beam_channels(np.ones((4, m_tx + 1)), p)
+
+
+def test_pathloss_matches_reference_formula():
+    """Dataset.compute_pathloss (dataset.py:541-566), restated inline in NumPy with the reference's dtypes."""
+    import deepmimo_amd as dm
+    from oracle import oracle_np as onp
+    rays = onp.synth_rays(500, 25, seed=91)
+    rays["power"][7, 3] = np.nan                                   # NaN in the middle of a row
+    ds = dm.Dataset(dict(rays))
+    for coherent in (True, False):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            g = np.sqrt(10 ** (rays["power"] / 10)).astype(np.complex64)
+            if coherent:
+                g = g * np.exp(1j * np.deg2rad(rays["phase"]))
+            tp = np.abs(np.nansum(g, axis=1)) ** 2
+            want = np.full_like(tp, np.nan)
+            want[tp > 0] = -10 * np.log10(tp[tp > 0])
+        got = ds.compute_pathloss(coherent)
+        assert got.dtype == np.float32 and got.shape == (500,)
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        np.testing.assert_allclose(got[~np.isnan(want)], want[~np.isnan(want)], rtol=0, atol=2e-4)   # dB
+    assert ds.pl is ds.pathloss
