@@ -205,7 +205,7 @@ def main():
                      "algorithmic_bytes_per_launch": n_ue * bytes_per_user},
     }
     if rank == 0 and world == 1:
-        cpu_users = args.cpu_users if args.cpu_users >= 0 else {"c3_headline": 200, "c2_asu_shape": 1000,
+        cpu_users = args.cpu_users if args.cpu_users >= 0 else {"c3_headline": 800, "c2_asu_shape": 4000,
                                                                 "c5_massive": 8, "tiny": 100}[args.workload]
         if cpu_users > 0:
             res["cpu_baseline"] = cpu_baseline(w, cpu_users)

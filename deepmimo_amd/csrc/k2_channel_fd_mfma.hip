@@ -400,6 +400,10 @@ static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user
     const size_t smem = (size_t)2 * a.rows * ROW_BYTES + LPAD * (8 + 4 + 4) + 16;
     const int64_t blocks = user_count * a.nblk;
     if (blocks > 0x7fffffffLL) { set_error("too many workgroups for one call"); return DMX_ERR_SHAPE; }
+    if ((size_t)a.rows * (size_t)a.K * 8 >= (size_t)1 << 31) {      // buffer descriptor / 32-bit offsets per row block
+        set_error("%d selected subcarriers are too many for one 256-row block", a.K);
+        return DMX_ERR_SHAPE;
+    }
     switch (config) {
         case 1: return launch_mfma_t<false, 16, 1>(ws, a, blocks, smem, out, stream);   // plain stores
         case 2: return launch_mfma_t<true, 4, 1>(ws, a, blocks, smem, out, stream);

@@ -129,6 +129,9 @@ SHAPES = [
     (9, 32, [16, 2], [1, 2], 64, list(range(64)), {}),
     (6, 25, [16, 16], [4, 4], 1024, list(range(0, 1024, 16)), dict(all_valid=True, max_delay=90e-6)),
     (5, 12, [70, 1], [1, 1], 64, list(range(64)), {}),
+    (11, 9, [6, 4], [2, 1], 80, list(range(2, 68, 2)), {}),                   # 48 rows, odd K = 33 on the MFMA kernel
+    (7, 5, [8, 4], [1, 1], 64, [5], {}),                                      # a single subcarrier
+    (6, 4, [3, 3], [3, 3], 32, [31, -1, 32, 95], {}),                         # indices outside 0..N-1 are plain integers
 ]
 
 
