@@ -240,7 +240,8 @@ class ChannelEngine:
                                                     C.c_void_p(bws.data_ptr() + off), nbytes,
                                                     C.c_void_p(out.data_ptr()), self._stream_ptr())
                 nat.check(rc, "dmx_channels_fd_beams")
-                prep.keepalive.extend([bws, cb])
+                # bws / cb may go out of scope now: the launch is on torch's current stream and the caching
+                # allocator reuses freed blocks in stream order, so the kernels still own them when they run
             elif p.freq_domain and p.rx_filter:
                 nbytes = int(self.lib.dmx_lpf_workspace_bytes(C.byref(p), user_count, prep.n_paths_loaded))
                 lws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
@@ -249,7 +250,6 @@ class ChannelEngine:
                                                   user_count, C.c_void_p(lws.data_ptr() + off), nbytes,
                                                   C.c_void_p(out.data_ptr()), self._stream_ptr())
                 nat.check(rc, "dmx_channels_fd_lpf")
-                prep.keepalive.append(lws)
             elif p.freq_domain:
                 rc = self.lib.dmx_channels_fd(C.byref(p), wsp, prep.n_ue, prep.n_paths_loaded, user_begin, user_count,
                                               C.c_void_p(out.data_ptr()), int(variant), self._stream_ptr())

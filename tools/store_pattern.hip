@@ -101,6 +101,24 @@ __global__ __launch_bounds__(1024) void pattern_tiles(float* __restrict__ out, f
     }
 }
 
+// mode 8: dwordx2 per lane, one store = 4 rows x 128 B (what a lane-pair exchange of the accumulator would give)
+__global__ __launch_bounds__(1024) void pattern_pairs(float* __restrict__ out, float v) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* o = out + (size_t)blockIdx.x * 256 * 1024;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(o, 0, 256 * 1024 * 4, 0x00020000);
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const u2 d = {__builtin_bit_cast(unsigned, v), 7u};
+    const int hh = lane >> 5, odd = lane & 1, c2 = (lane & 31) >> 1;      // 16 column pairs
+    for (int strip = wave; strip < 32; strip += 16) {
+        const unsigned lane_off = ((unsigned)(4 * hh + odd) * 1024u + (unsigned)(strip * 32 + c2 * 2)) * 4u;
+        for (int pt = 0; pt < 8; ++pt)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)                                     // row pairs (0,1),(2,3),(8,9),...
+                __builtin_amdgcn_raw_buffer_store_b64(d, rs, lane_off,
+                                                      (unsigned)(pt * 32 + ((2 * i) & 3) + 8 * ((2 * i) >> 2)) * 4096u, 2);
+    }
+}
+
 int main() {
     const int users = 100000;
     float* out;
@@ -108,7 +126,7 @@ int main() {
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
     const double gb = (double)users * 256 * 1024 * 4 / 1e9;
-    for (int mode = 0; mode < 8; ++mode) {
+    for (int mode = 0; mode < 9; ++mode) {
         float best = 1e9f;
         for (int rep = 0; rep < 4; ++rep) {
             hipEventRecord(a);
@@ -120,6 +138,7 @@ int main() {
             if (mode == 5) pattern_linear<false><<<users * 64, 256>>>((float4*)out, 1.f);
             if (mode == 6) pattern_tiles<0><<<users, 1024>>>(out, 1.f);
             if (mode == 7) pattern_linear<true><<<users * 64, 256>>>((float4*)out, 1.f);
+            if (mode == 8) pattern_pairs<<<users, 1024>>>(out, 1.f);
             hipEventRecord(b);
             hipEventSynchronize(b);
             float ms; hipEventElapsedTime(&ms, a, b);
