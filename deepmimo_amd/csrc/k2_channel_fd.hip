@@ -237,8 +237,12 @@ int launch_channels_fd(const dmx_params& prm, const WsView& ws, int64_t user_beg
     return launch_fd_valu_any(prm, ws, user_begin, user_count, nullptr, out, stream);
 }
 
+int launch_channels_fd_mfma_gload(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
+                                  const float2* gtab, float2* out, hipStream_t stream);
+
 int launch_channels_fd_lpf_contract(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
                                     const float2* gtab, float2* out, hipStream_t stream) {
+    if (fd_mfma_preferred(prm, ws)) return launch_channels_fd_mfma_gload(prm, ws, user_begin, user_count, gtab, out, stream);
     return launch_fd_valu_any(prm, ws, user_begin, user_count, gtab, out, stream);
 }
 

@@ -54,6 +54,8 @@ struct MfmaArgs {
     int n_beams;             // 0 = plain channel
     const float2* ftab;      // [user_count, n_beams, P]  f[b,l] = sum_tx F[b,tx] a_tx[tx,l]
     const int32_t* fexp;     // [user_count]              exponent of max |f| per user
+    // rx_filter variant: per-path subcarrier gains precomputed by k3_lpf_* instead of generated here
+    const float2* gtab;      // [user_count, P, K] or nullptr
 };
 
 // (x0, x1) -> packed hi pair and packed lo pair, x = hi + lo.  v_cvt_pkrtz_f16_f32 converts two floats per
@@ -70,6 +72,7 @@ __device__ __forceinline__ void split2_f16(float x0, float x1, h2& hi, h2& lo) {
 // K-step s is row kk = 16s + 8h + j of B', i.e. path l = 8s + 4h + (j>>1), component j&1.
 __device__ __forceinline__ void gen_b_fragments(int strip, int col, int hh, size_t twoK, const int32_t* __restrict__ sc,
                                                 int n_act, const double* qtab, const float* crtab, const float* citab,
+                                                const float2* __restrict__ grow, int K, float gs,
                                                 h8 (&Bhi)[4], h8 (&Blo)[4], bool& kok, unsigned& lane_off) {
     const int ncol = (strip << 5) + col;                                // column of C = 2*kidx + c
     const int kidx = ncol >> 1, c = ncol & 1;
@@ -87,11 +90,17 @@ __device__ __forceinline__ void gen_b_fragments(int strip, int col, int hh, size
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int pl = 8 * s + 4 * hh + 2 * c + t;
-                float sn, cs;
-                sincos_rev(frac_rev(qtab[pl] * kk), sn, cs);
-                const float cr = crtab[pl], ci = citab[pl];
-                mr[t] = cr * cs + ci * sn;                              // Re c*exp(-j x)
-                mi[t] = ci * cs - cr * sn;                              // Im
+                if (grow) {                                             // rx_filter: G[l,k] from the k3 table
+                    float2 g = make_float2(0.f, 0.f);
+                    if (kok && pl < n_act) g = grow[(size_t)pl * K + kidx];
+                    mr[t] = g.x * gs; mi[t] = g.y * gs;
+                } else {
+                    float sn, cs;
+                    sincos_rev(frac_rev(qtab[pl] * kk), sn, cs);
+                    const float cr = crtab[pl], ci = citab[pl];
+                    mr[t] = cr * cs + ci * sn;                          // Re c*exp(-j x)
+                    mi[t] = ci * cs - cr * sn;                          // Im
+                }
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t) { orr[t] = __shfl_xor(mr[t], 1); oi[t] = __shfl_xor(mi[t], 1); }
@@ -161,7 +170,9 @@ __global__ __launch_bounds__(NW * 64) void k2_fd_mfma(WsView ws, MfmaArgs a, flo
         // A' scale: 64 for unit-modulus array responses; with a codebook the projected responses f are
         // scaled per user so that max |f| lands in [32, 64)
         const int ea = a.n_beams ? 6 - a.fexp[ul] : 6;
-        if (lane == 0) { misc[0] = ldexpf(1.0f, e - 10 - ea); misc[1] = ldexpf(1.0f, ea); }   // 1 / (gs * A scale)
+        // rx_filter: |G| can exceed |c| by the sinc sum (a few x); two bits of headroom keep G*gs < 2^13
+        if (a.gtab) e += 2;
+        if (lane == 0) { misc[0] = ldexpf(1.0f, e - 10 - ea); misc[1] = ldexpf(1.0f, ea); misc[2] = ldexpf(1.0f, 10 - e); }
     }
 
     // phase 1: A' tiles.  thread = (row = antenna pair, slice of the path slots)
@@ -209,6 +220,8 @@ __global__ __launch_bounds__(NW * 64) void k2_fd_mfma(WsView ws, MfmaArgs a, flo
     }
     __syncthreads();
     const float oscale = misc[0];
+    const float gscale = misc[2];
+    const float2* grow = a.gtab ? a.gtab + (size_t)ul * ws.P * a.K : nullptr;
 
     const int col = lane & 31, hh = lane >> 5;
     const unsigned row_bytes = (unsigned)twoK * 4u;
@@ -225,7 +238,7 @@ __global__ __launch_bounds__(NW * 64) void k2_fd_mfma(WsView ws, MfmaArgs a, flo
         bool kok[SPW];
 #pragma unroll
         for (int j = 0; j < SPW; ++j)
-            gen_b_fragments(grp * SPW + j, col, hh, twoK, a.sc, n_act, qtab, crtab, citab, Bhi[j], Blo[j], kok[j], lane_off[j]);
+            gen_b_fragments(grp * SPW + j, col, hh, twoK, a.sc, n_act, qtab, crtab, citab, grow, a.K, gscale, Bhi[j], Blo[j], kok[j], lane_off[j]);
 
         for (int pt = 0; pt < ntiles; ++pt) {
             f16v acc[SPW];
@@ -327,7 +340,7 @@ __global__ __launch_bounds__(256) void k2b_beam_project(WsView ws, BeamArgs a) {
 }
 
 bool fd_mfma_supported(const dmx_params& prm, const WsView& ws) {
-    return ws.P <= LPAD && prm.n_selected >= 1 && !prm.rx_filter;
+    return ws.P <= LPAD && prm.n_selected >= 1;
 }
 
 // automatic choice: the matrix-core kernel pays off once a 32-row tile is mostly full
@@ -350,11 +363,17 @@ static int launch_mfma_t(const WsView& ws, const MfmaArgs& a, int64_t blocks, si
 }
 
 static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
-                           float2* out, int config, int n_beams, const float2* ftab, const int32_t* fexp, hipStream_t stream);
+                           float2* out, int config, int n_beams, const float2* ftab, const int32_t* fexp,
+                           const float2* gtab, hipStream_t stream);
+
+int launch_channels_fd_mfma_gload(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
+                                  const float2* gtab, float2* out, hipStream_t stream) {
+    return launch_mfma_any(prm, ws, user_begin, user_count, out, 0, 0, nullptr, nullptr, gtab, stream);
+}
 
 int launch_channels_fd_mfma(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
                             float2* out, int config, hipStream_t stream) {
-    return launch_mfma_any(prm, ws, user_begin, user_count, out, config, 0, nullptr, nullptr, stream);
+    return launch_mfma_any(prm, ws, user_begin, user_count, out, config, 0, nullptr, nullptr, nullptr, stream);
 }
 
 size_t beam_workspace_bytes(int64_t user_count, int n_beams, int P) {
@@ -378,13 +397,14 @@ int launch_channels_fd_beams(const dmx_params& prm, const WsView& ws, int64_t us
     hipLaunchKernelGGL(k2b_beam_project, dim3((unsigned)user_count), dim3(256), smem, stream, ws, b);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("k2b_beam_project launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
-    return launch_mfma_any(prm, ws, user_begin, user_count, out, 0, n_beams, b.ftab, b.fexp, stream);
+    return launch_mfma_any(prm, ws, user_begin, user_count, out, 0, n_beams, b.ftab, b.fexp, nullptr, stream);
 }
 
 static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
-                           float2* out, int config, int n_beams, const float2* ftab, const int32_t* fexp, hipStream_t stream) {
+                           float2* out, int config, int n_beams, const float2* ftab, const int32_t* fexp,
+                           const float2* gtab, hipStream_t stream) {
     MfmaArgs a;
-    a.n_beams = n_beams; a.ftab = ftab; a.fexp = fexp;
+    a.n_beams = n_beams; a.ftab = ftab; a.fexp = fexp; a.gtab = gtab;
     a.user_begin = user_begin;
     a.m_rx = prm.ue_shape[0] * prm.ue_shape[1];
     a.m_tx = prm.bs_shape[0] * prm.bs_shape[1];

@@ -388,3 +388,27 @@ def test_pathloss_matches_reference_formula():
         assert np.array_equal(np.isnan(got), np.isnan(want))
         np.testing.assert_allclose(got[~np.isnan(want)], want[~np.isnan(want)], rtol=0, atol=2e-4)   # dB
     assert ds.pl is ds.pathloss
+
+
+@pytest.mark.parametrize("N,K", [(512, 512), (256, 100), (96, 96)])
+def test_rx_filter_fft_and_mfma_path(N, K):
+    """rx_filter = 1 at shapes where the FFT form of the gains (power-of-two N) and the MFMA contraction with
+    table-loaded gains are used (M = 128 rows), plus a non-power-of-two N on the direct kernel; with Doppler."""
+    import deepmimo_amd as dm
+    from oracle import oracle_np as onp
+    rays = onp.synth_rays(24, 25, seed=N + K, max_delay=N / 10e6 * 1.1, with_doppler=True)
+    sel = np.arange(K) if K == N else np.sort(np.random.default_rng(K).choice(N, K, replace=False))
+    case = dict(bs_shape=[8, 4], ue_shape=[2, 2], bs_spacing=0.5, ue_spacing=0.5, bs_rot=[0, 10, 45],
+                bs_pattern="isotropic", ue_pattern="isotropic", num_paths=25, freq_domain=1, subcarriers=N,
+                selected=list(sel), bandwidth=10e6, rx_filter=1, bs_fov=None, ue_fov=None)
+    ue_rot = np.array([0, 0, 0])
+    op = oracle_params(case, ue_rot)
+    for dop in (0, 1):
+        op["enable_doppler"] = dop
+        ref = onp.compute_channels(rays, op, doppler=dict(vel=rays["doppler_vel"], acc=rays["doppler_acc"], carrier_freq=28e9))
+        ds = dm.Dataset(dict(rays))
+        ds["rt_params"] = {"frequency": 28e9}
+        p = _dm_params(case, ue_rot)
+        p.enable_doppler = dop
+        H = ds.compute_channels(p)
+        assert_channel_close(H, ref["channel"], what=f"lpf N={N} K={K} doppler={dop}")
