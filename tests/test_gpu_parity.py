@@ -412,3 +412,29 @@ def test_rx_filter_fft_and_mfma_path(N, K):
         p.enable_doppler = dop
         H = ds.compute_channels(p)
         assert_channel_close(H, ref["channel"], what=f"lpf N={N} K={K} doppler={dop}")
+
+
+def test_sionna_export_of_time_domain_channels():
+    """(a, tau) samples in Sionna's layout (reference: integrations/sionna_adapter.py:174-200) from TD channels."""
+    import deepmimo_amd as dm
+    from deepmimo_amd.sionna_adapter import DeepMIMOSionnaAdapter
+    from oracle import oracle_np as onp
+    rays = [onp.synth_rays(12, 6, seed=40 + b) for b in range(2)]
+    p = dm.ChannelGenParameters()
+    p.bs_antenna.shape, p.ue_antenna.shape, p.freq_domain, p.num_paths = np.array([4, 1]), np.array([2, 1]), 0, 6
+    md = dm.MacroDataset([dm.Dataset(dict(r)) for r in rays])
+    md.compute_channels(p)
+    ad = DeepMIMOSionnaAdapter(md, bs_idx=np.array([[0, 1]]), ue_idx=np.array([[0, 1, 2], [3, 4, 5]]))
+    assert len(ad) == 2 and ad.ch_shape == (3, 2, 2, 4, 6, 1) and ad.t_shape == (3, 2, 6)
+    samples = list(ad())
+    assert len(samples) == 2
+    a, tau = samples[1]
+    assert a.dtype == np.complex64 and tau.dtype == np.float32
+    np.testing.assert_array_equal(a[2, :, 1, :, :, 0], md[1].channel[5])
+    valid = ~np.isnan(rays[1]["power"][5])
+    np.testing.assert_array_equal(tau[2, 1, :valid.sum()], rays[1]["delay"][5][valid])
+    assert np.all(tau[2, 1, valid.sum():] == 0)
+    p.freq_domain = 1
+    md.compute_channels(p)
+    with pytest.raises(ValueError):
+        DeepMIMOSionnaAdapter(md)
