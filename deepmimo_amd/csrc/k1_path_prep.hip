@@ -41,6 +41,7 @@ struct PrepArgs {
     float ts32;                            // float32(1/bandwidth)
     int doppler;
     int rx_filter;
+    int need_angles;                       // angles wanted as numbers (side outputs, FoV, dipole), not just directions
     double fc;
 };
 
@@ -82,9 +83,13 @@ __device__ __forceinline__ void np_sincosf(float x, float& s_out, float& c_out) 
     c_out = (iqc & 2) ? -cv : cv;
 }
 
-// geometry.py:284-310 for one path
-__device__ __forceinline__ void rotate_one(float el_deg, float az_deg, double sx, double cx, double sy,
-                                           double cy, double rz, double& th, double& ph) {
+// geometry.py:284-310 for one path: the rotated direction as (cos zenith', re, im) with
+//   zenith' = arccos(zc)  (geometry.py:305-306),  azimuth' = angle(re + j im)  (geometry.py:308-310).
+// The angles themselves are only materialised when something needs them (side outputs, FoV, dipole
+// pattern); the array-response steps use sin(zenith') = sqrt(1 - zc^2), sin(azimuth') = im / |re + j im|
+// and cos(zenith') = zc, which are the same numbers without three float64 trig calls per array side.
+__device__ __forceinline__ void rotate_dir(float el_deg, float az_deg, double sx, double cx, double sy,
+                                           double cy, double rz, double& zc, double& re, double& im) {
     const float th32 = el_deg * D2R_F;
     const float ph32 = az_deg * D2R_F;
     float st32, ct32;
@@ -93,10 +98,9 @@ __device__ __forceinline__ void rotate_one(float el_deg, float az_deg, double sx
     const double d = (double)ph32 - rz;
     double sd, cd;
     sincos(d, &sd, &cd);
-    th = acos(cy * cx * ct + st * (sy * cx * cd - sx * sd));
-    const double re = cy * st * cd - sy * ct;
-    const double im = cy * sx * ct + st * (sy * sx * cd + cx * sd);
-    ph = atan2(im, re);
+    zc = cy * cx * ct + st * (sy * cx * cd - sx * sd);
+    re = cy * st * cd - sy * ct;
+    im = cy * sx * ct + st * (sy * sx * cd + cx * sd);
 }
 
 // np.mod(x, 2pi): result takes the sign of the divisor
@@ -179,9 +183,16 @@ __global__ __launch_bounds__(256) void k1_path_prep(PrepArgs a) {
         const float aod_el = in ? r.aod_el[row + j] : nan32;
         const float inter = in ? r.inter[row + j] : nan32;
 
-        double th_t, ph_t, th_r, ph_r;
-        rotate_one(aod_el, aod_az, a.bsx, a.csx, a.bsy, a.csy, a.brz, th_t, ph_t);
-        rotate_one(aoa_el, aoa_az, usx, ucx, usy, ucy, urz, th_r, ph_r);
+        double zc_t, re_t, im_t, zc_r, re_r, im_r;
+        rotate_dir(aod_el, aod_az, a.bsx, a.csx, a.bsy, a.csy, a.brz, zc_t, re_t, im_t);
+        rotate_dir(aoa_el, aoa_az, usx, ucx, usy, ucy, urz, zc_r, re_r, im_r);
+        // arccos is NaN outside [-1, 1]; np.angle is NaN only for NaN input
+        double th_t = (isnan(zc_t) || fabs(zc_t) > 1.0) ? nan64 : 0.0, ph_t = (isnan(re_t) || isnan(im_t)) ? nan64 : 0.0;
+        double th_r = (isnan(zc_r) || fabs(zc_r) > 1.0) ? nan64 : 0.0, ph_r = (isnan(re_r) || isnan(im_r)) ? nan64 : 0.0;
+        if (a.need_angles) {                                 // wave-uniform
+            th_t = acos(zc_t); ph_t = atan2(im_t, re_t);
+            th_r = acos(zc_r); ph_r = atan2(im_r, re_r);
+        }
         if (in) {
             if (a.side.aod_el_rot) a.side.aod_el_rot[srow + j] = th_t;
             if (a.side.aod_az_rot) a.side.aod_az_rot[srow + j] = ph_t;
@@ -271,9 +282,10 @@ __global__ __launch_bounds__(256) void k1_path_prep(PrepArgs a) {
             keep = valid;                                                  // slot even if coefficient is 0
         }
         double ty = 0.0, tz = 0.0, ry = 0.0, rz = 0.0;
-        if (ang_ok) {
-            ty = a.bs_spacing * (sin(th_t) * sin(ph_t)); tz = a.bs_spacing * cos(th_t);
-            ry = a.ue_spacing * (sin(th_r) * sin(ph_r)); rz = a.ue_spacing * cos(th_r);
+        if (ang_ok) {                                        // geometry.py:99-101 in revolutions (kd / 2pi = spacing)
+            const double rho_t = sqrt(re_t * re_t + im_t * im_t), rho_r = sqrt(re_r * re_r + im_r * im_r);
+            ty = a.bs_spacing * (sqrt(1.0 - zc_t * zc_t) * (rho_t > 0.0 ? im_t / rho_t : 0.0)); tz = a.bs_spacing * zc_t;
+            ry = a.ue_spacing * (sqrt(1.0 - zc_r * zc_r) * (rho_r > 0.0 ? im_r / rho_r : 0.0)); rz = a.ue_spacing * zc_r;
         }
         const unsigned long long kb = group_mask<LPU>(__ballot(keep), grp);
         if (keep) {
@@ -298,7 +310,13 @@ __global__ __launch_bounds__(256) void k1_path_prep(PrepArgs a) {
             const bool has = a.fov_enabled ? has_fov_path : (count_paths > 0);
             a.side.los[u] = has ? ((first_inter == 0.0f) ? 1 : 0) : -1;    // dataset.py:604-609
         }
-        if (a.side.max_delay_key && anyd) atomicMax(a.side.max_delay_key, float_order_key(maxd));
+        // one running maximum for the whole launch: a returning atomic per user would serialise 1e5 updates on
+        // one L2 word (~88 per us), so look first (relaxed, L2-served) and only update when this user raises it
+        if (a.side.max_delay_key && anyd) {
+            const uint32_t key = float_order_key(maxd);
+            if (key > __hip_atomic_load(a.side.max_delay_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(a.side.max_delay_key, key);
+        }
     }
 }
 
@@ -320,6 +338,8 @@ int launch_path_prep(const dmx_rays& rays, const dmx_params& prm, const WsView& 
     a.P = ws.P; a.freq_domain = prm.freq_domain; a.n_sc = prm.n_subcarriers;
     a.ts32 = (float)(1.0 / prm.bandwidth);
     a.doppler = prm.enable_doppler; a.fc = prm.carrier_freq; a.rx_filter = prm.rx_filter && prm.freq_domain;
+    a.need_angles = prm.fov_enabled || prm.bs_pattern != DMX_PATTERN_ISOTROPIC || prm.ue_pattern != DMX_PATTERN_ISOTROPIC ||
+                    side.aod_el_rot || side.aod_az_rot || side.aoa_el_rot || side.aoa_az_rot;
     if (rays.n_ue == 0) return DMX_OK;
     if (rays.n_paths <= 32) {
         const unsigned grid = (unsigned)((rays.n_ue + 7) / 8);
