@@ -179,6 +179,22 @@ class Dataset(DotDict):
         self[c.CHANNEL_PARAM_NAME] = out
         return out
 
+    def iter_channels(self, params: Optional[ChannelGenParameters] = None, chunk_users: int = 4096):
+        """Generate channels in user chunks (extension): yields ``(user_begin, H_chunk)`` with ``H_chunk`` a
+        NumPy complex64 array [<= chunk_users, M_rx, M_tx, K].  For scenarios whose full tensor (1 MB per user at
+        64x4 antennas x 512 subcarriers) fits neither host memory nor one NumPy array; stage 1 runs once, stage 2
+        per chunk through the C-ABI's user_begin / user_count range.  Nothing is cached as ``channel``."""
+        if params is None:
+            params = ChannelGenParameters() if self._data.get(c.CH_PARAMS_PARAM_NAME) is None else self.ch_params
+        self.set_channel_params(params)
+        np.random.seed(1001)
+        eng, prep = self._run_prep(want_side=True)
+        n = prep.n_ue
+        variant = int(config.get("fd_kernel_variant", 0))
+        for b in range(0, n, max(1, int(chunk_users))):
+            cnt = min(int(chunk_users), n - b)
+            yield b, eng.channels(prep, user_begin=b, user_count=cnt, variant=variant).cpu().numpy()
+
     def compute_beam_channels(self, codebook, params: Optional[ChannelGenParameters] = None):
         """Beam-space channels ``codebook @ H`` for a TX codebook [n_beams, M_tx] (rows e.g. from
         ``dm.steering_vec``), complex64 [n_ue, M_rx, n_beams, K] - what docs/manual.ipynb cell 105 computes

@@ -438,3 +438,19 @@ def test_sionna_export_of_time_domain_channels():
     md.compute_channels(p)
     with pytest.raises(ValueError):
         DeepMIMOSionnaAdapter(md)
+
+
+def test_iter_channels_chunks_equal_full_tensor():
+    import deepmimo_amd as dm
+    from oracle import oracle_np as onp
+    rays = onp.synth_rays(205, 9, seed=17)
+    p = dm.ChannelGenParameters()
+    p.bs_antenna.shape = np.array([8, 4])
+    p.ofdm.selected_subcarriers = np.arange(0, 512, 11)
+    ds = dm.Dataset(dict(rays))
+    H = ds.compute_channels(p)
+    seen = 0
+    for b, chunk in ds.iter_channels(p, chunk_users=64):
+        assert b == seen and np.array_equal(chunk, H[b:b + chunk.shape[0]])
+        seen += chunk.shape[0]
+    assert seen == 205
