@@ -1,4 +1,4 @@
-// Stage 2, frequency domain - split-precision MFMA kernel (variant 2; the default for M >= 32).
+// Stage 2, frequency domain - split-precision MFMA kernel (variant 2; the automatic choice for M >= 24 rows, K >= 8).
 //
 // Per user the channel block is a skinny complex GEMM  H[p, k] = sum_l A[p,l] * G[l,k]  with
 //   p = (rx, tx) antenna pair (M = M_rx*M_tx rows),  A[p,l] = a_rx[rx,l] * a_tx[tx,l]   (unit modulus)
