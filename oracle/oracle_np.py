@@ -131,6 +131,35 @@ def array_response_batch(shape, spacing, theta, phi) -> np.ndarray:
     return np.where(ok[:, None, :], a, 0.0 + 0.0j)
 
 
+# scalar (per-user) twins: the reference keeps both forms and its tests compare them
+# (test/test_rotate_angles.py, test/test_fov.py, test/test_array_response.py); so does tests/test_oracle_golden.py
+def rotate_angles_scalar(rotation_deg, theta_deg, phi_deg):
+    """One user's paths, one rotation triple (geometry.py:198-241).  rotation None = degrees to radians only."""
+    th, ph = np.deg2rad(theta_deg), np.deg2rad(phi_deg)
+    if rotation_deg is None:
+        return th, ph
+    rx, ry, rz = np.deg2rad(rotation_deg)
+    d = ph - rz
+    st, ct = np.sin(th), np.cos(th)
+    th_rot = np.arccos(np.cos(ry) * np.cos(rx) * ct + st * (np.sin(ry) * np.cos(rx) * np.cos(d) - np.sin(rx) * np.sin(d)))
+    ph_rot = np.angle(np.cos(ry) * st * np.cos(d) - np.sin(ry) * ct +
+                      1j * (np.cos(ry) * np.sin(rx) * ct + st * (np.sin(ry) * np.sin(rx) * np.cos(d) + np.cos(rx) * np.sin(d))))
+    return th_rot, ph_rot
+
+
+def fov_mask_scalar(fov_deg, theta, phi) -> np.ndarray:
+    """geometry.py:123-159 (same arithmetic as the batch form, 1-D inputs)."""
+    return fov_mask_batch(fov_deg, np.asarray(theta), np.asarray(phi))
+
+
+def array_response_scalar(shape, spacing, theta: float, phi: float) -> np.ndarray:
+    """[M] response of one path (geometry.py:19-35)."""
+    idx = ant_indices(shape)
+    kd = 2 * np.pi * spacing
+    gamma = 1j * kd * np.array([np.sin(theta) * np.cos(phi), np.sin(theta) * np.sin(phi), np.cos(theta)])
+    return np.exp(idx @ gamma)
+
+
 def steering_vec(shape, phi=0.0, theta=0.0, spacing=0.5) -> np.ndarray:
     """Normalised beam-steering vector [M, 1] (geometry.py:322-339).
 

@@ -153,3 +153,36 @@ def test_numpy_f32_sincos_model():
     cos_m = np.where(iqc & 2, -np.where(iqc & 1, cp, sp), np.where(iqc & 1, cp, sp)).astype(f32)
     assert np.array_equal(sin_m, np.sin(x))
     assert np.array_equal(cos_m, np.cos(x))
+
+
+def test_batch_forms_equal_scalar_forms():
+    """The reference's own test idea (test/test_rotate_angles.py:10-127, test/test_fov.py:10-155,
+    test/test_array_response.py:8-50): vectorised == per-user, including per-user rotations and NaN padding."""
+    rng = np.random.default_rng(11)
+    n, L = 9, 7
+    th = rng.uniform(0, 180, (n, L)).astype(np.float32)
+    ph = rng.uniform(-180, 180, (n, L)).astype(np.float32)
+    th[3, 4:] = np.nan
+    ph[3, 4:] = np.nan
+    rot = rng.uniform(-90, 90, (n, 3))
+    tb, pb = onp.rotate_angles_batch(rot, th, ph)
+    for i in range(n):
+        ts, ps = onp.rotate_angles_scalar(rot[i], th[i], ph[i])
+        np.testing.assert_array_equal(tb[i], ts)
+        np.testing.assert_array_equal(pb[i], ps)
+    tb1, pb1 = onp.rotate_angles_batch(np.array([30, 40, 30]), th, ph)
+    ts1, ps1 = onp.rotate_angles_scalar(np.array([30, 40, 30]), th[2], ph[2])
+    np.testing.assert_array_equal(tb1[2], ts1)
+    np.testing.assert_array_equal(pb1[2], ps1)
+    with np.errstate(invalid="ignore"):
+        mb = onp.fov_mask_batch(np.array([140, 120]), tb, pb)
+        for i in range(n):
+            np.testing.assert_array_equal(mb[i], onp.fov_mask_scalar(np.array([140, 120]), tb[i], pb[i]))
+    a = onp.array_response_batch([4, 2], 0.5, tb, pb)
+    for i in (0, 3, 8):
+        for l in range(L):
+            if np.isnan(tb[i, l]):
+                assert np.all(a[i, :, l] == 0)
+            else:
+                np.testing.assert_allclose(a[i, :, l], onp.array_response_scalar([4, 2], 0.5, tb[i, l], pb[i, l]),
+                                           rtol=1e-10, atol=1e-12)          # test_array_response.py: rtol 1e-10
