@@ -14,7 +14,8 @@ ABI_VERSION = 1
 EXPORTED_SYMBOLS = ("dmx_version", "dmx_last_error", "dmx_workspace_bytes", "dmx_decode_max_delay",
                     "dmx_path_prep", "dmx_channels_fd", "dmx_channels_td", "dmx_channels_fd_lpf",
                     "dmx_lpf_workspace_bytes", "dmx_mat5_find", "dmx_mat_to_rowmajor_f32",
-                    "dmx_beam_workspace_bytes", "dmx_channels_fd_beams", "dmx_pathloss")
+                    "dmx_beam_workspace_bytes", "dmx_channels_fd_beams", "dmx_pathloss",
+                    "dmx_p2m_count_rx", "dmx_p2m_parse_paths")
 
 PATTERN_IDS = {"isotropic": 0, "halfwave-dipole": 1}
 
@@ -101,6 +102,10 @@ def load():
     lib.dmx_channels_fd_beams.restype = C.c_int
     lib.dmx_channels_fd_beams.argtypes = [C.POINTER(DmxParams), C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64,
                                           C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.dmx_p2m_count_rx.restype = C.c_int64
+    lib.dmx_p2m_count_rx.argtypes = [C.c_void_p, C.c_size_t]
+    lib.dmx_p2m_parse_paths.restype = C.c_int
+    lib.dmx_p2m_parse_paths.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_int64] + [C.c_void_p] * 9
     lib.dmx_pathloss.restype = C.c_int
     lib.dmx_pathloss.argtypes = [C.POINTER(DmxRays), C.c_int32, C.c_void_p, C.c_void_p]
     lib.dmx_mat5_find.restype = C.c_int

@@ -197,6 +197,18 @@ int dmx_mat5_find(const void* file_image, size_t len, const char* var_name, dmx_
 int dmx_mat_to_rowmajor_f32(const void* d_payload, int32_t data_type, int64_t rows, int64_t cols,
                             const int64_t* d_row_idx, int64_t n_sel, int32_t cols_keep, float* d_out, void* stream);
 
+/* ---- two steps before the path: Wireless InSite paths.p2m text -> ray matrices ----- */
+
+/* Receiver count announced on line 22 of a `*.paths.*.p2m` file image (p2m_parser.py:36, 80); -1 on error. */
+int64_t dmx_p2m_count_rx(const char* text, size_t len);
+
+/* Host-side parse of a `*.paths.*.p2m` file image into NaN-padded float32 matrices [n_rx, max_paths]
+ * (inter_pos: [n_rx, max_paths, max_inter, 3], may be NULL).  Replaces paths_parser,
+ * deepmimo/converter/wireless_insite/p2m_parser.py:48-145, before its compress_path_data step. */
+int dmx_p2m_parse_paths(const char* text, size_t len, int32_t max_paths, int32_t max_inter, int64_t n_rx,
+                        float* aoa_az, float* aoa_el, float* aod_az, float* aod_el, float* delay, float* power,
+                        float* phase, float* inter, float* inter_pos);
+
 #ifdef __cplusplus
 }
 #endif

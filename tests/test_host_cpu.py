@@ -199,3 +199,27 @@ def test_mat5_parser_finds_payload(tmp_path):
     assert lib.dmx_mat5_find(C.c_char_p(raw), len(raw), b"nope", C.byref(info)) != 0
     assert b"not found" in lib.dmx_last_error()
     assert lib.dmx_mat5_find(C.c_char_p(b"x" * 200), 200, None, C.byref(info)) != 0
+
+
+def test_p2m_parser_matches_reference_parser(tmp_path):
+    """dmx_p2m_parse_paths (host C++) against what the REAL reference parser returned for the same synthetic
+    Wireless InSite paths file (tests/golden/p2m_paths.npz, made by oracle/gen_p2m_golden.py)."""
+    from deepmimo_amd.p2m import paths_parser
+    z = np.load(os.path.join(ROOT, "tests", "golden", "p2m_paths.npz"), allow_pickle=False)
+    path = tmp_path / "synthetic.paths.t001_01.r002.p2m"
+    path.write_text(str(z["p2m_text"]))
+    got = paths_parser(str(path))
+    keys = [k[4:] for k in z.files if k.startswith("ref_")]
+    assert set(keys) == set(got.keys())
+    for k in keys:
+        assert got[k].dtype == z["ref_" + k].dtype == np.float32
+        np.testing.assert_array_equal(got[k], z["ref_" + k], err_msg=k)
+    # a receiver with more paths than max_paths: surplus paths are skipped, the following receiver still parses
+    few = paths_parser(str(path), max_paths=3)
+    n = min(3, got["power"].shape[1])
+    np.testing.assert_array_equal(few["power"][:, :n], got["power"][:, :n])
+    bad = tmp_path / "bad.p2m"
+    bad.write_text("only one line\n")
+    from deepmimo_amd._native import NativeError
+    with pytest.raises(NativeError):
+        paths_parser(str(bad))
