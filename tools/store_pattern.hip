@@ -119,6 +119,18 @@ __global__ __launch_bounds__(1024) void pattern_pairs(float* __restrict__ out, f
     }
 }
 
+// mode 9: dword per lane, one store = ONE row x 256 B (two adjacent strips merged with v_permlane32_swap)
+__global__ __launch_bounds__(1024) void pattern_row256(float* __restrict__ out, float v) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* o = out + (size_t)blockIdx.x * 256 * 1024;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(o, 0, 256 * 1024 * 4, 0x00020000);
+    const unsigned lane_off = (unsigned)(wave * 64 + lane) * 4u;            // 16 waves x 64 columns = the 1024-float row
+    for (int pt = 0; pt < 8; ++pt)
+#pragma unroll
+        for (int i = 0; i < 32; ++i)                                         // 32 rows of the tile, one per store
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + i), rs, lane_off, (unsigned)(pt * 32 + i) * 4096u, 2);
+}
+
 int main() {
     const int users = 100000;
     float* out;
@@ -126,7 +138,7 @@ int main() {
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
     const double gb = (double)users * 256 * 1024 * 4 / 1e9;
-    for (int mode = 0; mode < 9; ++mode) {
+    for (int mode = 0; mode < 10; ++mode) {
         float best = 1e9f;
         for (int rep = 0; rep < 4; ++rep) {
             hipEventRecord(a);
@@ -139,6 +151,7 @@ int main() {
             if (mode == 6) pattern_tiles<0><<<users, 1024>>>(out, 1.f);
             if (mode == 7) pattern_linear<true><<<users * 64, 256>>>((float4*)out, 1.f);
             if (mode == 8) pattern_pairs<<<users, 1024>>>(out, 1.f);
+            if (mode == 9) pattern_row256<<<users, 1024>>>(out, 1.f);
             hipEventRecord(b);
             hipEventSynchronize(b);
             float ms; hipEventElapsedTime(&ms, a, b);
