@@ -154,8 +154,11 @@ int launch_channels_fd_lpf(const dmx_params& prm, const WsView& ws, int64_t user
         if (pow2) {
             int log2n = 0;
             while ((1 << log2n) < a.N) ++log2n;
-            int PB = 512 / a.N;                               // keep 256 threads busy: PB*N/2 >= 256 butterflies
+            // paths transformed together: every stage costs one workgroup barrier whatever PB is, so batch as
+            // many paths as 32 KiB of LDS hold (8 at N = 512) - 25 paths then need 4 x 9 barriers instead of 25 x 9
+            int PB = 4096 / a.N;
             if (PB < 1) PB = 1;
+            if (PB > 16) PB = 16;
             if (PB > ws.P) PB = ws.P;
             const size_t smem = (size_t)(a.N / 2) * 8 + (size_t)PB * a.N * 8 + (size_t)PB * 4;
             hipLaunchKernelGGL(k3_lpf_fft, dim3((unsigned)user_count), dim3(256), smem, stream, ws, a, log2n, PB);

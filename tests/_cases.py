@@ -18,7 +18,7 @@ TOL_ABS = 1e-12
 
 
 def golden_names():
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "g[0-9]*.npz")))
 
 
 def load_golden(name):
