@@ -339,6 +339,123 @@ __global__ __launch_bounds__(256) void k2b_beam_project(WsView ws, BeamArgs a) {
     }
 }
 
+// Matrix-core form of the projection (used when the codebook fits LDS: B <= 128 beams, B*M_tx <= ~7.5k):
+// per user the [B x M_tx] . [M_tx x L] complex product is the same interleaved real GEMM as the main
+// contraction, f'[b][2l+c] = sum_kk F'[b][kk] T'[kk][2l+c] with kk = 2tx + {re, im}.  The codebook's hi/lo f16
+// split (scaled so max|F| is in [512, 1024)) is staged ONCE per persistent workgroup; each wave then takes
+// users in turn, builds the a_tx B'-fragments of one K-step in registers (lane = (path, re/im) column, lane
+// pairs share the sin/cos work as in gen_b_fragments) and issues 3 MFMAs per 32-beam tile and K-step:
+// 96 MFMAs + ~130 sin/cos pairs per user at 64 beams x 64 elements, instead of 1e5 scalar complex MACs.
+template <int NBT>
+__global__ __launch_bounds__(256) void k2b_beam_project_mfma(WsView ws, BeamArgs a, int64_t user_count, int kkpad, int fstride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Fhi = smem;                                              // [NBT*32][fstride]
+    unsigned char* Flo = smem + (size_t)NBT * 32 * fstride;
+    __shared__ float wmax_s[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = a.n_beams, P = ws.P;
+
+    // codebook -> LDS (hi/lo f16), scaled by the power of two that puts max |F| component in [512, 1024)
+    float m = 0.f;
+    for (int i = tid; i < B * a.m_tx; i += 256) { const float2 w = a.F[i]; m = fmaxf(m, fmaxf(fabsf(w.x), fabsf(w.y))); }
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (lane == 0) wmax_s[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(wmax_s[0], wmax_s[1]), fmaxf(wmax_s[2], wmax_s[3]));
+    int eF = 0;
+    if (m > 0.f) (void)frexpf(m, &eF);
+    const float sF = ldexpf(1.0f, 10 - eF);
+    const float oscale = ldexpf(1.0f, eF - 10 - 6);                          // 1 / (sF * A_SCALE)
+    const int half_kk = kkpad >> 1;
+    for (int i = tid; i < NBT * 32 * half_kk; i += 256) {
+        const int b = i / half_kk, t = i - b * half_kk;
+        h2 vh = {(_Float16)0.f, (_Float16)0.f}, vl = vh;
+        if (b < B && t < a.m_tx) {
+            const float2 w = a.F[(size_t)b * a.m_tx + t];
+            split2_f16(w.x * sF, w.y * sF, vh, vl);
+        }
+        reinterpret_cast<h2*>(Fhi + (size_t)b * fstride)[t] = vh;
+        reinterpret_cast<h2*>(Flo + (size_t)b * fstride)[t] = vl;
+    }
+    __syncthreads();
+
+    const int colr = lane & 31, hh = lane >> 5, c = lane & 1;
+    const int ksteps = kkpad >> 4;
+    for (int64_t ul = (int64_t)blockIdx.x * 4 + wave; ul < user_count; ul += (int64_t)gridDim.x * 4) {
+        const int64_t u = a.user_begin + ul;
+        int n_act = ws.n_keep[u];
+        n_act = n_act < LPAD ? n_act : LPAD;
+        const size_t rb = (size_t)u * P;
+        float* fout = reinterpret_cast<float*>(a.ftab + (size_t)ul * B * P);     // [B][P] complex = [B][2P] floats
+        float wmax = 0.f;
+        const int nct = (2 * n_act + 31) >> 5;
+        for (int ct = 0; ct < nct; ++ct) {
+            const int col = (ct << 5) + colr, l = col >> 1;
+            const bool lok = l < n_act;
+            const double ty = lok ? ws.tx_y[rb + l] : 0.0, tz = lok ? ws.tx_z[rb + l] : 0.0;
+            f16v acc[NBT];
+#pragma unroll
+            for (int bt = 0; bt < NBT; ++bt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[bt][i] = 0.f;
+            for (int s = 0; s < ksteps; ++s) {
+                // B' fragment of this K-step: rows kk = 16s + 8h + j  <->  element tx = 8s + 4h + (j>>1), part j&1
+                float mr[2], mi[2], orr[2], oi[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int tx = 8 * s + 4 * hh + 2 * c + t;
+                    float sn = 0.f, cs = 0.f;
+                    if (lok && tx < a.m_tx) {
+                        sincos_rev(frac_rev((double)(tx % a.bs_mh) * ty + (double)(tx / a.bs_mh) * tz), sn, cs);
+                        sn *= A_SCALE; cs *= A_SCALE;
+                    }
+                    mr[t] = cs; mi[t] = sn;
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) { orr[t] = __shfl_xor(mr[t], 1); oi[t] = __shfl_xor(mi[t], 1); }
+                float gr[4], gi[4];
+                gr[0] = c ? orr[0] : mr[0]; gi[0] = c ? oi[0] : mi[0];
+                gr[1] = c ? orr[1] : mr[1]; gi[1] = c ? oi[1] : mi[1];
+                gr[2] = c ? mr[0] : orr[0]; gi[2] = c ? mi[0] : oi[0];
+                gr[3] = c ? mr[1] : orr[1]; gi[3] = c ? mi[1] : oi[1];
+                h8 Bh, Bl;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float e0 = c ? gi[jj] : gr[jj];
+                    const float e1 = c ? gr[jj] : -gi[jj];
+                    h2 ph, pl2;
+                    split2_f16(e0, e1, ph, pl2);
+                    Bh[2 * jj] = ph[0]; Bh[2 * jj + 1] = ph[1];
+                    Bl[2 * jj] = pl2[0]; Bl[2 * jj + 1] = pl2[1];
+                }
+#pragma unroll
+                for (int bt = 0; bt < NBT; ++bt) {
+                    const size_t aoff = (size_t)((bt << 5) + colr) * fstride + (size_t)s * 32 + (size_t)hh * 16;
+                    const h8 ah = *reinterpret_cast<const h8*>(Fhi + aoff);
+                    const h8 al = *reinterpret_cast<const h8*>(Flo + aoff);
+                    acc[bt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bh, acc[bt], 0, 0, 0);
+                    acc[bt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bl, acc[bt], 0, 0, 0);
+                    acc[bt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bh, acc[bt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int bt = 0; bt < NBT; ++bt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int b = (bt << 5) + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    const float v = acc[bt][i] * oscale;
+                    if (lok && b < B) { fout[(size_t)b * 2 * P + col] = v; wmax = fmaxf(wmax, fabsf(v)); }
+                }
+        }
+        for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off));
+        if (lane == 0) {
+            int e = 0;
+            if (wmax > 0.f) (void)frexpf(wmax, &e);
+            a.fexp[ul] = e;
+        }
+    }
+}
+
 bool fd_mfma_supported(const dmx_params& prm, const WsView& ws) {
     return ws.P <= LPAD && prm.n_selected >= 1;
 }
@@ -392,9 +509,22 @@ int launch_channels_fd_beams(const dmx_params& prm, const WsView& ws, int64_t us
     b.ftab = reinterpret_cast<float2*>(beam_ws);
     b.fexp = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(beam_ws) +
                                         align_up((size_t)user_count * (size_t)n_beams * (size_t)ws.P * 8, 256));
-    const size_t smem = (size_t)b.m_tx * (ws.P > 0 ? ws.P : 1) * 8;
-    if (smem > 64 * 1024) { set_error("BS panel of %d elements x %d paths does not fit the beam-projection table", b.m_tx, ws.P); return DMX_ERR_SHAPE; }
-    hipLaunchKernelGGL(k2b_beam_project, dim3((unsigned)user_count), dim3(256), smem, stream, ws, b);
+    // matrix-core projection when the codebook's f16 hi/lo image fits 64 KiB of LDS, scalar kernel otherwise
+    const int kkpad = (2 * b.m_tx + 15) / 16 * 16;
+    const int fstride = kkpad * 2 + 16;
+    const int nbt = (n_beams + 31) / 32;
+    const size_t smem_m = (size_t)2 * (nbt <= 1 ? 1 : (nbt <= 2 ? 2 : 4)) * 32 * fstride;
+    if (nbt <= 4 && smem_m <= 64 * 1024) {
+        int64_t grid = (user_count + 3) / 4;
+        if (grid > 2048) grid = 2048;                      // persistent: the codebook is staged once per workgroup
+        if (nbt <= 1) hipLaunchKernelGGL(k2b_beam_project_mfma<1>, dim3((unsigned)grid), dim3(256), smem_m, stream, ws, b, user_count, kkpad, fstride);
+        else if (nbt <= 2) hipLaunchKernelGGL(k2b_beam_project_mfma<2>, dim3((unsigned)grid), dim3(256), smem_m, stream, ws, b, user_count, kkpad, fstride);
+        else hipLaunchKernelGGL(k2b_beam_project_mfma<4>, dim3((unsigned)grid), dim3(256), smem_m, stream, ws, b, user_count, kkpad, fstride);
+    } else {
+        const size_t smem = (size_t)b.m_tx * (ws.P > 0 ? ws.P : 1) * 8;
+        if (smem > 64 * 1024) { set_error("BS panel of %d elements x %d paths does not fit the beam-projection table", b.m_tx, ws.P); return DMX_ERR_SHAPE; }
+        hipLaunchKernelGGL(k2b_beam_project, dim3((unsigned)user_count), dim3(256), smem, stream, ws, b);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("k2b_beam_project launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
     return launch_mfma_any(prm, ws, user_begin, user_count, out, 0, n_beams, b.ftab, b.fexp, nullptr, stream);
