@@ -10,7 +10,7 @@ path delays of one or several ``Dataset`` objects (one per basestation).  Index 
 """
 from __future__ import annotations
 
-from typing import Iterator, List, Optional, Sequence, Tuple
+from typing import Iterator, List, Tuple
 
 import numpy as np
 

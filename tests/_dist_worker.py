@@ -2,7 +2,6 @@
 import os
 import sys
 
-import numpy as np
 import torch
 import torch.distributed as dist
 

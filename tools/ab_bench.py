@@ -23,9 +23,14 @@ def main():
     ap.add_argument("--workload", default="c3_headline")
     ap.add_argument("--users", type=int, default=0)
     ap.add_argument("--random-valid", action="store_true")
+    ap.add_argument("--shape", type=int, nargs=6, metavar=("BS0", "BS1", "UE0", "UE1", "L", "N"), default=None,
+                    help="custom shape instead of --workload (all N subcarriers selected)")
     ap.add_argument("--beams", type=int, default=0, help="also time the fused beam-space kernel with this many beams")
     args = ap.parse_args()
     w = dict(bench.WORKLOADS[args.workload])
+    if args.shape:
+        b0, b1, u0, u1, L, N = args.shape
+        w = dict(n_ue=w["n_ue"], bs=[b0, b1], ue=[u0, u1], L=L, N=N)
     if args.users:
         w["n_ue"] = args.users
     dev = torch.device("cuda", 0)

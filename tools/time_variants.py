@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timing of the non-default variants (rx_filter, time domain, Doppler) at the headline antenna/path shape."""
 import os, sys
-import numpy as np, torch
+import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from deepmimo_amd.engine import ChannelEngine
