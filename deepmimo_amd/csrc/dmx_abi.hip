@@ -149,7 +149,7 @@ int dmx_channels_fd_beams(const dmx_params* prm, const void* workspace, int64_t 
     if (!prm->freq_domain || prm->rx_filter) { set_error("dmx_channels_fd_beams needs freq_domain = 1 and rx_filter = 0"); return DMX_ERR_ARG; }
     if (n_beams < 0 || (n_beams > 0 && !codebook_c64)) { set_error("codebook missing"); return DMX_ERR_ARG; }
     if (prm->n_selected == 0 || n_beams == 0) return DMX_OK;
-    if (!fd_mfma_supported(*prm, ws)) { set_error("num_paths = %d exceeds the 32 paths the beam-space kernel supports", ws.P); return DMX_ERR_SHAPE; }
+    if (ws.P > 32) { set_error("num_paths = %d exceeds the 32 paths the beam-space kernel supports", ws.P); return DMX_ERR_SHAPE; }
     const size_t need = beam_workspace_bytes(user_count, n_beams, ws.P);
     if (!beam_workspace || beam_workspace_bytes_ < need || ((uintptr_t)beam_workspace & 255u)) {
         set_error("beam workspace too small or misaligned: need %zu bytes, 256-byte aligned", need);

@@ -32,6 +32,8 @@ struct FdArgs {
     double inv_n;
     int txt;        // transmit elements per LDS tile
     const float2* gtab;   // rx_filter variant: precomputed path gains [user_count, P, K] (k3_lpf_gains.hip)
+    int l0;               // first path slot of this pass (users with more than 32 kept paths take several passes)
+    int accumulate;       // 1: add to what earlier passes wrote
 };
 
 // Everything one workgroup does for one user with LPA (multiple of 4) path slots; slots beyond the
@@ -43,7 +45,7 @@ __device__ __forceinline__ void fd_user(const WsView& ws, const FdArgs& a, float
     float* brx = reinterpret_cast<float*>(q + LPA);             // [m_rx][2*LPA]
     float* atx = brx + (size_t)a.m_rx * 2 * LPA;                // [txt][2*LPA]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const size_t rb = (size_t)u * ws.P;
+    const size_t rb = (size_t)u * ws.P + a.l0;
 
     if (tid < LPA) q[tid] = tid < n_act ? (double)ws.dn[rb + tid] * a.inv_n : 0.0;
     for (int i = tid; i < a.m_rx * LPA; i += 256) {
@@ -87,7 +89,7 @@ __device__ __forceinline__ void fd_user(const WsView& ws, const FdArgs& a, float
             for (int l = 0; l < LPA; ++l) {
                 if constexpr (GLOAD) {
                     float2 v = make_float2(0.f, 0.f);
-                    if (kok && l < n_act) v = a.gtab[((size_t)blockIdx.x * ws.P + l) * a.K + kidx];
+                    if (kok && l < n_act) v = a.gtab[((size_t)blockIdx.x * ws.P + a.l0 + l) * a.K + kidx];
                     g_re[l] = v.x; g_im[l] = v.y;
                 } else {
                     float s, c;
@@ -132,9 +134,12 @@ __device__ __forceinline__ void fd_user(const WsView& ws, const FdArgs& a, float
                     if (kok) {
 #pragma unroll
                         for (int b = 0; b < RB; ++b) {
-                            if (rx0 + b < a.m_rx)
-                                o[((size_t)(rx0 + b) * a.m_tx + (tx0 + tx)) * a.K + kidx] =
-                                    make_float2(accA[b].x - accB[b].y, accA[b].y + accB[b].x);
+                            if (rx0 + b < a.m_rx) {
+                                float2* dst = o + ((size_t)(rx0 + b) * a.m_tx + (tx0 + tx)) * a.K + kidx;
+                                float2 v = make_float2(accA[b].x - accB[b].y, accA[b].y + accB[b].x);
+                                if (a.accumulate) { const float2 prev = *dst; v.x += prev.x; v.y += prev.y; }
+                                *dst = v;
+                            }
                         }
                     }
                 }
@@ -152,10 +157,11 @@ __global__ __launch_bounds__(256, 2) void k2_fd_valu(WsView ws, FdArgs a, float2
     const int64_t u = a.user_begin + blockIdx.x;
     const size_t per_user = (size_t)a.m_rx * a.m_tx * a.K;
     float2* __restrict__ o = out + (size_t)blockIdx.x * per_user;
-    int n_act = ws.n_keep[u];
+    int n_act = ws.n_keep[u] - a.l0;
     n_act = n_act < LPMAX ? n_act : LPMAX;
-    if (n_act == 0) {                                            // channel.py:270-271: stays all-zero
-        for (size_t i = tid; i < per_user; i += 256) o[i] = make_float2(0.f, 0.f);
+    if (n_act <= 0) {                                            // channel.py:270-271: stays all-zero
+        if (!a.accumulate)
+            for (size_t i = tid; i < per_user; i += 256) o[i] = make_float2(0.f, 0.f);
         return;
     }
     const int n4 = (n_act + 3) >> 2;
@@ -189,8 +195,9 @@ static int launch_valu(const WsView& ws, const FdArgs& a0, int64_t user_count, f
 }
 
 static int launch_fd_valu_any(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
-                              const float2* gtab, float2* out, hipStream_t stream) {
+                              const float2* gtab, float2* out, hipStream_t stream, int l0 = 0, int accumulate = 0) {
     FdArgs a;
+    a.l0 = l0; a.accumulate = accumulate;
     a.user_begin = user_begin;
     a.m_rx = prm.ue_shape[0] * prm.ue_shape[1];
     a.m_tx = prm.bs_shape[0] * prm.bs_shape[1];
@@ -201,7 +208,7 @@ static int launch_fd_valu_any(const dmx_params& prm, const WsView& ws, int64_t u
     a.inv_n = 1.0 / (double)prm.n_subcarriers;
     a.txt = 0;
     a.gtab = gtab;
-    const int P = ws.P;
+    const int P = (ws.P - l0) < 32 ? (ws.P - l0) : 32;       // path slots of this pass
     // RB = receive elements sharing one a_tx row read.  2 halves the LDS traffic but doubles the t
     // registers; beyond 16 path slots that would spill, so the long-path bodies use RB = 1.
     const bool rb2 = a.m_rx >= 2;
@@ -216,8 +223,20 @@ static int launch_fd_valu_any(const dmx_params& prm, const WsView& ws, int64_t u
         if (P <= 28) return launch_valu<28, 1>(ws, a, user_count, out, stream);
         if (P <= 32) return launch_valu<32, 1>(ws, a, user_count, out, stream);
     }
-    set_error("num_paths = %d exceeds the %d paths the frequency-domain kernel supports", P, 32);
+    set_error("internal: %d path slots in one pass", P);
     return DMX_ERR_SHAPE;
+}
+
+// More than 32 path slots (beyond DeepMIMO's MAX_PATHS = 25, but allowed): the first 32 slots go through the
+// chosen kernel, every further block of 32 through the fp32 vector kernel in accumulate mode (users whose kept
+// paths ended earlier return at once).  The output is read back once per extra pass - the price of the rare case.
+static int launch_extra_path_passes(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
+                                    const float2* gtab, float2* out, hipStream_t stream) {
+    for (int l0 = 32; l0 < ws.P; l0 += 32) {
+        int rc = launch_fd_valu_any(prm, ws, user_begin, user_count, gtab, out, stream, l0, 1);
+        if (rc) return rc;
+    }
+    return DMX_OK;
 }
 
 int launch_channels_fd_mfma(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
@@ -232,9 +251,12 @@ int launch_channels_fd(const dmx_params& prm, const WsView& ws, int64_t user_beg
         set_error("MFMA variant does not support this shape");
         return DMX_ERR_SHAPE;
     }
+    int rc;
     if (variant >= 2 || (variant == 0 && fd_mfma_preferred(prm, ws)))
-        return launch_channels_fd_mfma(prm, ws, user_begin, user_count, out, variant >= 3 ? variant - 2 : 0, stream);
-    return launch_fd_valu_any(prm, ws, user_begin, user_count, nullptr, out, stream);
+        rc = launch_channels_fd_mfma(prm, ws, user_begin, user_count, out, variant >= 3 ? variant - 2 : 0, stream);
+    else
+        rc = launch_fd_valu_any(prm, ws, user_begin, user_count, nullptr, out, stream);
+    return rc ? rc : launch_extra_path_passes(prm, ws, user_begin, user_count, nullptr, out, stream);
 }
 
 int launch_channels_fd_mfma_gload(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
@@ -242,8 +264,10 @@ int launch_channels_fd_mfma_gload(const dmx_params& prm, const WsView& ws, int64
 
 int launch_channels_fd_lpf_contract(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
                                     const float2* gtab, float2* out, hipStream_t stream) {
-    if (fd_mfma_preferred(prm, ws)) return launch_channels_fd_mfma_gload(prm, ws, user_begin, user_count, gtab, out, stream);
-    return launch_fd_valu_any(prm, ws, user_begin, user_count, gtab, out, stream);
+    int rc;
+    if (fd_mfma_preferred(prm, ws)) rc = launch_channels_fd_mfma_gload(prm, ws, user_begin, user_count, gtab, out, stream);
+    else rc = launch_fd_valu_any(prm, ws, user_begin, user_count, gtab, out, stream);
+    return rc ? rc : launch_extra_path_passes(prm, ws, user_begin, user_count, gtab, out, stream);
 }
 
 }  // namespace dmx

@@ -457,7 +457,8 @@ __global__ __launch_bounds__(256) void k2b_beam_project_mfma(WsView ws, BeamArgs
 }
 
 bool fd_mfma_supported(const dmx_params& prm, const WsView& ws) {
-    return ws.P <= LPAD && prm.n_selected >= 1;
+    (void)ws;               // any path count: this kernel takes the first 32 kept paths, k2_channel_fd.hip adds the rest
+    return prm.n_selected >= 1;
 }
 
 // automatic choice: the matrix-core kernel pays off once a 32-row tile is mostly full

@@ -288,14 +288,11 @@ def test_errors_are_loud():
     p.ofdm.bandwidth = 0.0
     with pytest.raises(NativeError):
         ds.compute_channels(p)
-    wide = dm.Dataset(dict(onp.synth_rays(4, 40, seed=9)))           # more than 32 paths: unsupported, loudly
+    wide = dm.Dataset(dict(onp.synth_rays(4, 40, seed=9)))           # beam-space kernel: at most 32 paths, loudly
     p = dm.ChannelGenParameters()
     p.num_paths = 40
     with pytest.raises(NativeError, match="32 paths"):
-        wide.compute_channels(p)
-    p.num_paths = 25                                                   # ... but 40 loaded / 25 used is fine
-    assert wide.compute_channels(p).shape == (4, 1, 8, 1)
-    assert wide.num_paths.max() <= 40
+        wide.compute_beam_channels(np.ones((2, 8)), p)
     dm.config("use_gpu", False)
     try:
         with pytest.raises(RuntimeError):
@@ -454,3 +451,24 @@ def test_iter_channels_chunks_equal_full_tensor():
         assert b == seen and np.array_equal(chunk, H[b:b + chunk.shape[0]])
         seen += chunk.shape[0]
     assert seen == 205
+
+
+@pytest.mark.parametrize("L,bs,ue,lpf", [(40, [4, 2], [1, 1], 0), (70, [8, 8], [2, 1], 0), (45, [8, 4], [1, 2], 1)])
+def test_more_than_32_paths(L, bs, ue, lpf):
+    """Beyond DeepMIMO's MAX_PATHS = 25: path slots past 32 are added by accumulate passes (k2_channel_fd.hip),
+    on top of either kernel and of the rx_filter table."""
+    import deepmimo_amd as dm
+    from oracle import oracle_np as onp
+    rays = onp.synth_rays(30, L, seed=L)
+    case = dict(bs_shape=bs, ue_shape=ue, bs_spacing=0.5, ue_spacing=0.5, bs_rot=[0, 0, 30], bs_pattern="isotropic",
+                ue_pattern="isotropic", num_paths=L, freq_domain=1, subcarriers=64, selected=list(range(0, 64, 3)),
+                bandwidth=10e6, rx_filter=lpf, bs_fov=None, ue_fov=None)
+    ue_rot = np.array([0, 0, 0])
+    ref = onp.compute_channels(rays, oracle_params(case, ue_rot))
+    ds = dm.Dataset(dict(rays))
+    H = ds.compute_channels(_dm_params(case, ue_rot))
+    assert_channel_close(H, ref["channel"], what=f"{L} paths")
+    np.testing.assert_array_equal(ds.num_paths, ref["num_paths"])
+    case["freq_domain"] = 0
+    ref = onp.compute_channels(rays, oracle_params(case, ue_rot))
+    assert_channel_close(ds.compute_channels(_dm_params(case, ue_rot)), ref["channel"], what=f"{L} paths, time domain")
