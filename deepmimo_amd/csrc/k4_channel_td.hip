@@ -2,9 +2,11 @@
 // for the s-th valid path of user u (valid paths compacted to the front), zero for the remaining
 // slots.  Replaces the TD branch of _generate_MIMO_channel (channel.py:285-287).
 //
-// The output is only [M_rx, M_tx, P] per user (P <= 25), so this is a plain HBM-store-bound
-// elementwise kernel: thread = output element (slot fastest => contiguous complex64 stores), the
-// element's phase is the float64 sum of its four index x step products, range-reduced once.
+// The output is only [M_rx, M_tx, P] per user (P <= 25): an HBM-store-bound elementwise kernel,
+// thread = output element (slot fastest => contiguous complex64 stores).  k4_td_tab first builds the two
+// factor tables b_rx[r][s] = c_s a_rx[r,s] and a_tx[t][s] in LDS (float64-range-reduced phases, one sin/cos
+// per table entry instead of one per output element) and multiplies them out; k4_td is the table-free form
+// for panels whose tables exceed LDS.
 #include "dmx_common.h"
 
 namespace dmx {
@@ -40,6 +42,43 @@ __global__ __launch_bounds__(256) void k4_td(WsView ws, TdArgs a, float2* __rest
     }
 }
 
+__global__ __launch_bounds__(256) void k4_td_tab(WsView ws, TdArgs a, float2* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int P = ws.P;
+    float2* brx = reinterpret_cast<float2*>(smem);          // [m_rx][P]
+    float2* atx = brx + (size_t)a.m_rx * P;                 // [m_tx][P]
+    const int64_t u = a.user_begin + blockIdx.x;
+    const size_t per_user = (size_t)a.m_rx * a.m_tx * P;
+    float2* __restrict__ o = out + (size_t)blockIdx.x * per_user;
+    const int n_keep = ws.n_keep[u];
+    const size_t rb = (size_t)u * P;
+    for (int i = threadIdx.x; i < (a.m_rx + a.m_tx) * P; i += 256) {
+        const int e = i / P, s = i - e * P;                 // e < m_rx: receive element, else transmit element
+        float2 v = make_float2(0.f, 0.f);
+        if (s < n_keep) {
+            float sn, cs;
+            if (e < a.m_rx) {
+                sincos_rev(frac_rev((double)(e % a.ue_mh) * ws.rx_y[rb + s] + (double)(e / a.ue_mh) * ws.rx_z[rb + s]), sn, cs);
+                const float cr = ws.c_re[rb + s], ci = ws.c_im[rb + s];
+                v = make_float2(cr * cs - ci * sn, cr * sn + ci * cs);
+            } else {
+                const int t = e - a.m_rx;
+                sincos_rev(frac_rev((double)(t % a.bs_mh) * ws.tx_y[rb + s] + (double)(t / a.bs_mh) * ws.tx_z[rb + s]), sn, cs);
+                v = make_float2(cs, sn);
+            }
+        }
+        brx[i] = v;                                         // the two tables are contiguous
+    }
+    __syncthreads();
+    for (size_t i = threadIdx.x; i < per_user; i += 256) {
+        const int s = (int)(i % P);
+        const int m = (int)((i / P) % a.m_tx);
+        const int r = (int)(i / ((size_t)P * a.m_tx));
+        const float2 b = brx[r * P + s], t = atx[m * P + s];
+        o[i] = make_float2(b.x * t.x - b.y * t.y, b.x * t.y + b.y * t.x);
+    }
+}
+
 int launch_channels_td(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
                        float2* out, hipStream_t stream) {
     if (user_count == 0 || ws.P == 0) return DMX_OK;
@@ -49,7 +88,11 @@ int launch_channels_td(const dmx_params& prm, const WsView& ws, int64_t user_beg
     a.m_tx = prm.bs_shape[0] * prm.bs_shape[1];
     a.ue_mh = prm.ue_shape[0];
     a.bs_mh = prm.bs_shape[0];
-    hipLaunchKernelGGL(k4_td, dim3((unsigned)user_count), dim3(256), 0, stream, ws, a, out);
+    const size_t smem = (size_t)(a.m_rx + a.m_tx) * ws.P * 8;
+    if (smem <= 64 * 1024)
+        hipLaunchKernelGGL(k4_td_tab, dim3((unsigned)user_count), dim3(256), smem, stream, ws, a, out);
+    else
+        hipLaunchKernelGGL(k4_td, dim3((unsigned)user_count), dim3(256), 0, stream, ws, a, out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("k4_td launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
     return DMX_OK;
