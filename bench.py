@@ -71,19 +71,51 @@ def make_params(w):
     return p
 
 
-def cpu_baseline(w, sample_users):
-    """Reference-style CPU generator (per-user complex128 broadcast + nansum loop) on a user sample."""
+def _cpu_chunk(args):
+    """One worker's share of the CPU baseline (module-level so multiprocessing can pickle it)."""
+    w, n, seed = args
     from oracle import oracle_np as onp
-    rays = onp.synth_rays(sample_users, w["L"], seed=4321, all_valid=True)
+    rays = onp.synth_rays(n, w["L"], seed=seed, all_valid=True)
     op = onp.make_params(bs_antenna=dict(shape=w["bs"]), ue_antenna=dict(shape=w["ue"]), num_paths=w["L"],
                          ofdm=dict(subcarriers=w["N"], selected_subcarriers=np.arange(w["N"])))
     t0 = time.perf_counter()
     onp.compute_channels(rays, op, style="reference")
-    dt = time.perf_counter() - t0
-    return {"value": sample_users / dt, "unit": "user-channels/s", "cores": 1, "kind": "port",
-            "sample": f"{sample_users} users of the same workload shape, all paths valid, NumPy oracle "
-                      f"style='reference' (per-user complex128 broadcast+nansum loop), {dt:.1f} s, "
-                      f"host has {os.cpu_count()} logical cores"}
+    return time.perf_counter() - t0
+
+
+def cpu_baseline_here(w, sample_users, workers):
+    """Reference-style CPU generator (per-user complex128 broadcast + nansum loop, oracle/oracle_np.py
+    style='reference') on a user sample: one process (the reference's execution model), then - for fairness - the
+    same sample split over `workers` processes.  Runs in a process that never touches the GPU."""
+    _cpu_chunk((w, max(1, min(16, sample_users // 8)), 99))      # untimed warm-up (imports, allocator, page faults)
+    dt1 = _cpu_chunk((w, sample_users, 4321))
+    out = {"value": sample_users / dt1, "unit": "user-channels/s", "cores": 1, "kind": "port",
+           "sample": f"{sample_users} users of the same workload shape, all paths valid, NumPy oracle "
+                     f"style='reference' (per-user complex128 broadcast+nansum loop), {dt1:.1f} s, "
+                     f"host has {os.cpu_count()} logical cores"}
+    if workers > 1:
+        import multiprocessing as mp
+        per = max(1, sample_users // workers)
+        with mp.get_context("fork").Pool(workers) as pool:
+            t0 = time.perf_counter()
+            pool.map(_cpu_chunk, [(w, per, 5000 + i) for i in range(workers)])
+            dtw = time.perf_counter() - t0
+        out["all_cores"] = {"value": per * workers / dtw, "unit": "user-channels/s", "cores": workers,
+                            "sample": f"{workers} processes x {per} users, {dtw:.1f} s wall"}
+    return out
+
+
+def cpu_baseline(workload, users_override, sample_users, workers):
+    """Run the CPU baseline in a child process (no CUDA context there, so forking workers is safe)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", workload,
+           "--cpu-users", str(sample_users), "--cpu-workers", str(workers)]
+    if users_override:
+        cmd += ["--users", str(users_override)]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    if r.returncode != 0:
+        raise RuntimeError("cpu baseline failed:\n" + r.stderr[-2000:])
+    return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 def measured_traffic(workload, n_ue, variant):
@@ -111,7 +143,15 @@ def main():
     ap.add_argument("--users", type=int, default=0, help="override users per GPU")
     ap.add_argument("--cpu-users", type=int, default=-1, help="CPU baseline sample size (0 = skip)")
     ap.add_argument("--random-valid", action="store_true", help="valid paths per user uniform in 0..L")
+    ap.add_argument("--cpu-workers", type=int, default=-1, help="processes of the all-cores CPU figure (default min(16, cores))")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_workers < 0:
+        args.cpu_workers = min(16, os.cpu_count() or 1)      # a one-GPU box gives this job a 16-core share
+    if args.cpu_baseline_only:
+        w = dict(WORKLOADS[args.workload])
+        print(json.dumps(cpu_baseline_here(w, args.cpu_users, args.cpu_workers)))
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -208,7 +248,7 @@ def main():
         cpu_users = args.cpu_users if args.cpu_users >= 0 else {"c3_headline": 800, "c2_asu_shape": 4000,
                                                                 "c5_massive": 8, "tiny": 100}[args.workload]
         if cpu_users > 0:
-            res["cpu_baseline"] = cpu_baseline(w, cpu_users)
+            res["cpu_baseline"] = cpu_baseline(args.workload, 0, cpu_users, args.cpu_workers)
     if rank == 0:
         print(json.dumps(res))
     if dist:
