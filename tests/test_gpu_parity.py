@@ -4,6 +4,8 @@ produced and (b) the NumPy oracle on seeded synthetic rays.
 
 Tolerance (BASELINE.json north_star / SURVEY.md 8c): |dH| <= 5e-5 * max|H_ref[user]| + 1e-12;
 LoS, path counts and FoV masks bit-exact; power_linear rtol 1e-6."""
+import os
+
 import numpy as np
 import pytest
 
@@ -472,3 +474,27 @@ def test_more_than_32_paths(L, bs, ue, lpf):
     case["freq_domain"] = 0
     ref = onp.compute_channels(rays, oracle_params(case, ue_rot))
     assert_channel_close(ds.compute_channels(_dm_params(case, ue_rot)), ref["channel"], what=f"{L} paths, time domain")
+
+
+def test_cache_plumbing_sequence_matches_reference():
+    """The same SEQUENCE of Dataset API calls that oracle/gen_sequence_golden.py ran on the real reference
+    (lazy attribute before compute with a random UE-rotation range, rotation change, repeated compute, FoV reset
+    with lazy .channel, switch to time domain): every step must reproduce what the reference returned
+    (dataset.py:144-222, 250, 327-338, 358-378, 515-535)."""
+    import io
+    from contextlib import redirect_stdout
+    import deepmimo_amd as dm
+    from oracle.gen_sequence_golden import run_sequence
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "seq_cache_plumbing.npz"), allow_pickle=False)
+    rays = {k[4:]: z[k] for k in z.files if k.startswith("ray_")}
+    with redirect_stdout(io.StringIO()):
+        got = run_sequence(dm, rays)
+    for k in got:
+        ref = z["ref_" + k]
+        if k.endswith("channel"):
+            assert_channel_close(got[k], ref, what=k)
+        else:
+            np.testing.assert_array_equal(got[k], ref, err_msg=k)
+    # the three frequency-domain steps really differ from each other (the sequence is not vacuous)
+    assert not np.allclose(z["ref_s1_channel"], z["ref_s2_channel"])
+    assert np.array_equal(z["ref_s2_channel"], z["ref_s3_channel"])
