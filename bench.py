@@ -190,14 +190,24 @@ def main():
     m_rx, m_tx = w["ue"][0] * w["ue"][1], w["bs"][0] * w["bs"][1]
     out = torch.empty((n_ue, m_rx, m_tx, w["N"]), dtype=torch.complex64, device=dev)
 
+    # one preparation allocates the workspace once; every step then re-issues BOTH stages on the same buffers
+    # (ChannelEngine.relaunch: two C-ABI calls, no allocation, no host-device copy, no sync)
+    prep0 = eng.prepare(rays, params, want_side=False)
+    import ctypes as C
+    from deepmimo_amd import _native as nat
+
     def step(ev0=None, ev1=None):
-        prep = eng.prepare(rays, params, want_side=False)
+        p, wsp = prep0.params_struct, C.c_void_p(prep0.workspace.data_ptr())
+        stream = eng._stream_ptr()
+        prep0.side["max_delay_key"].zero_()
+        nat.check(eng.lib.dmx_path_prep(C.byref(prep0.rays_struct), C.byref(p), wsp, prep0.workspace_bytes,
+                                        C.byref(prep0.side_struct), stream), "dmx_path_prep")
         if ev0 is not None:
             ev0.record(torch.cuda.current_stream(dev))
-        eng.channels(prep, out=out, variant=args.variant)
+        nat.check(eng.lib.dmx_channels_fd(C.byref(p), wsp, prep0.n_ue, prep0.n_paths_loaded, 0, prep0.n_ue,
+                                          C.c_void_p(out.data_ptr()), int(args.variant), stream), "dmx_channels_fd")
         if ev1 is not None:
             ev1.record(torch.cuda.current_stream(dev))
-        return prep
 
     for _ in range(args.warmup):
         step()

@@ -50,6 +50,9 @@ class PrepResult:
     params_struct: nat.DmxParams
     keepalive: list = field(default_factory=list)
     side: Dict[str, torch.Tensor] = field(default_factory=dict)
+    rays_struct: Optional[nat.DmxRays] = None
+    side_struct: Optional[nat.DmxSide] = None
+    workspace_bytes: int = 0
 
 
 def is_full_fov(fov) -> bool:
@@ -191,7 +194,35 @@ class ChannelEngine:
                                         self._stream_ptr())
         nat.check(rc, "dmx_path_prep")
         keep.extend(rays.fields.values())
-        return PrepResult(workspace=ws, n_ue=n, n_paths_loaded=L, params_struct=p, keepalive=keep, side=side)
+        return PrepResult(workspace=ws, n_ue=n, n_paths_loaded=L, params_struct=p, keepalive=keep, side=side,
+                          rays_struct=r, side_struct=s, workspace_bytes=nbytes)
+
+    def relaunch(self, prep: PrepResult, out: torch.Tensor, variant: int = 0) -> torch.Tensor:
+        """Re-issue stage 1 + stage 2 of an existing preparation on the current stream, reading whatever the
+        ray tensors hold NOW.  No allocation, no host-device copy, no synchronisation: the two C-ABI calls only
+        enqueue kernels, so this is what a HIP graph captures (tests/test_gpu_parity.py::test_hip_graph_replay)
+        and what a serving loop calls per batch.  Frequency domain without rx_filter, or time domain."""
+        p = prep.params_struct
+        if p.freq_domain and p.rx_filter:
+            raise ValueError("relaunch does not cover rx_filter = 1 (it needs a gains table per call)")
+        shape = self.channel_shape(prep)
+        if out.dtype != torch.complex64 or tuple(out.shape) != shape or not out.is_contiguous():
+            raise ValueError(f"out must be a contiguous complex64 tensor of shape {shape}")
+        wsp = C.c_void_p(prep.workspace.data_ptr())
+        stream = self._stream_ptr()
+        with torch.cuda.device(self.device):
+            prep.side["max_delay_key"].zero_()
+            nat.check(self.lib.dmx_path_prep(C.byref(prep.rays_struct), C.byref(p), wsp, prep.workspace_bytes,
+                                             C.byref(prep.side_struct), stream), "dmx_path_prep")
+            if out.numel():
+                if p.freq_domain:
+                    rc = self.lib.dmx_channels_fd(C.byref(p), wsp, prep.n_ue, prep.n_paths_loaded, 0, prep.n_ue,
+                                                  C.c_void_p(out.data_ptr()), int(variant), stream)
+                else:
+                    rc = self.lib.dmx_channels_td(C.byref(p), wsp, prep.n_ue, prep.n_paths_loaded, 0, prep.n_ue,
+                                                  C.c_void_p(out.data_ptr()), stream)
+                nat.check(rc, "stage 2")
+        return out
 
     # ------------------------------------------------------------------ stage 2
     def channel_shape(self, prep: PrepResult, user_count: Optional[int] = None):

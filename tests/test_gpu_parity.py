@@ -498,3 +498,39 @@ def test_cache_plumbing_sequence_matches_reference():
     # the three frequency-domain steps really differ from each other (the sequence is not vacuous)
     assert not np.allclose(z["ref_s1_channel"], z["ref_s2_channel"])
     assert np.array_equal(z["ref_s2_channel"], z["ref_s3_channel"])
+
+
+def test_hip_graph_replay():
+    """The C-ABI calls only enqueue kernels (no allocation, no sync): stage 1 + stage 2 captured in a HIP graph and
+    replayed on new ray data give the same tensor as fresh eager calls."""
+    import torch
+    import deepmimo_amd as dm
+    from deepmimo_amd.engine import ChannelEngine
+    from oracle import oracle_np as onp
+    eng = ChannelEngine(0)
+    p = dm.ChannelGenParameters()
+    p.bs_antenna.shape, p.ue_antenna.shape = np.array([8, 4]), np.array([2, 1])
+    p.ofdm.selected_subcarriers = np.arange(0, 512, 8)
+    p.validate(64)
+    a, b = onp.synth_rays(64, 10, seed=1), onp.synth_rays(64, 10, seed=2)
+    rays = eng.upload_rays(a)
+    prep = eng.prepare(rays, p, want_side=True)
+    out = torch.empty(eng.channel_shape(prep), dtype=torch.complex64, device="cuda")
+    eng.relaunch(prep, out)                                   # warm-up outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        eng.relaunch(prep, out)
+    want_a = eng.channels(eng.prepare(eng.upload_rays(a), p, want_side=False)).clone()
+    want_b = eng.channels(eng.prepare(eng.upload_rays(b), p, want_side=False)).clone()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(torch.view_as_real(out), torch.view_as_real(want_a))
+    for k in dm.consts.RAY_FIELDS:                            # new batch lands in the SAME device buffers
+        rays.fields[k].copy_(torch.from_numpy(b[k]))
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(torch.view_as_real(out), torch.view_as_real(want_b))
+    assert np.array_equal(prep.side["los"].cpu().numpy(), onp.compute_channels(b, onp.make_params(
+        bs_antenna=dict(shape=[8, 4]), ue_antenna=dict(shape=[2, 1]),
+        ofdm=dict(selected_subcarriers=np.arange(0, 512, 8))))["los"])
