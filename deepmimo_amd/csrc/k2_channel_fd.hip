@@ -38,17 +38,30 @@ struct FdArgs {
 
 // Everything one workgroup does for one user with LPA (multiple of 4) path slots; slots beyond the
 // user's n_act paths hold zero table entries, so the unrolled loops need no guards.
-template <int LPA, int RB, bool GLOAD>
+// Synchronisation among the WPU waves that share one user's tables: a workgroup barrier for WPU = 4; for
+// WPU = 1 the wave's own LDS operations are already executed in order, so only the compiler has to be held back.
+template <int WPU>
+__device__ __forceinline__ void user_sync() {
+    if constexpr (WPU == 4) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int LPA, int RB, bool GLOAD, int WPU>
 __device__ __forceinline__ void fd_user(const WsView& ws, const FdArgs& a, float2* __restrict__ o, int64_t u,
-                                        int n_act, unsigned char* smem) {
+                                        int64_t u_local, int n_act, unsigned char* smem) {
+    constexpr int NTU = WPU * 64;                               // threads working on this user
     double* q = reinterpret_cast<double*>(smem);                 // [LPA]  dn_l / N
     float* brx = reinterpret_cast<float*>(q + LPA);             // [m_rx][2*LPA]
     float* atx = brx + (size_t)a.m_rx * 2 * LPA;                // [txt][2*LPA]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x % NTU, lane = tid & 63, wave = tid >> 6;
     const size_t rb = (size_t)u * ws.P + a.l0;
 
     if (tid < LPA) q[tid] = tid < n_act ? (double)ws.dn[rb + tid] * a.inv_n : 0.0;
-    for (int i = tid; i < a.m_rx * LPA; i += 256) {
+    for (int i = tid; i < a.m_rx * LPA; i += NTU) {
         const int r = i / LPA, l = i - r * LPA;
         float re = 0.f, im = 0.f;
         if (l < n_act) {
@@ -67,8 +80,8 @@ __device__ __forceinline__ void fd_user(const WsView& ws, const FdArgs& a, float
     const int nchunks = (a.K + 63) >> 6;
     for (int tx0 = 0; tx0 < a.m_tx; tx0 += a.txt) {
         const int ntx = (a.m_tx - tx0) < a.txt ? (a.m_tx - tx0) : a.txt;
-        __syncthreads();                                         // previous tile fully consumed
-        for (int i = tid; i < ntx * LPA; i += 256) {
+        user_sync<WPU>();                                        // previous tile fully consumed
+        for (int i = tid; i < ntx * LPA; i += NTU) {
             const int t = i / LPA, l = i - t * LPA;
             float s = 0.f, c = 0.f;
             if (l < n_act) {
@@ -78,9 +91,9 @@ __device__ __forceinline__ void fd_user(const WsView& ws, const FdArgs& a, float
             atx[(size_t)t * 2 * LPA + 2 * l] = c;
             atx[(size_t)t * 2 * LPA + 2 * l + 1] = s;
         }
-        __syncthreads();
+        user_sync<WPU>();
 
-        for (int ch = wave; ch < nchunks; ch += 4) {
+        for (int ch = wave; ch < nchunks; ch += WPU) {
             const int kidx = (ch << 6) + lane;
             const bool kok = kidx < a.K;
             const double kk = (double)(kok ? a.sc[kidx] : 0);
@@ -89,7 +102,7 @@ __device__ __forceinline__ void fd_user(const WsView& ws, const FdArgs& a, float
             for (int l = 0; l < LPA; ++l) {
                 if constexpr (GLOAD) {
                     float2 v = make_float2(0.f, 0.f);
-                    if (kok && l < n_act) v = a.gtab[((size_t)blockIdx.x * ws.P + a.l0 + l) * a.K + kidx];
+                    if (kok && l < n_act) v = a.gtab[((size_t)u_local * ws.P + a.l0 + l) * a.K + kidx];
                     g_re[l] = v.x; g_im[l] = v.y;
                 } else {
                     float s, c;
@@ -150,36 +163,44 @@ __device__ __forceinline__ void fd_user(const WsView& ws, const FdArgs& a, float
 
 // LPMAX = slots the launch provides LDS/registers for (>= P); each user runs the smallest body
 // that holds its n_act compacted paths (real ray-traced users have far fewer than P paths).
-template <int LPMAX, int RB, bool GLOAD>
-__global__ __launch_bounds__(256, 2) void k2_fd_valu(WsView ws, FdArgs a, float2* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x;
-    const int64_t u = a.user_begin + blockIdx.x;
+// WPU = waves per user: 4 (one user per 256-thread workgroup) or 1 (four users per workgroup, one wave each,
+// no workgroup barrier) for shapes whose subcarriers fit one 64-lane chunk - there three of four waves would
+// idle and the per-workgroup fixed costs (launch, table build, barriers) dominate the tiny per-user work.
+template <int LPMAX, int RB, bool GLOAD, int WPU>
+__global__ __launch_bounds__(256, 2) void k2_fd_valu(WsView ws, FdArgs a, float2* __restrict__ out, int64_t user_count,
+                                                     int smem_per_user) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    constexpr int UPW = 4 / WPU, NTU = WPU * 64;
+    const int slot = threadIdx.x / NTU, tid = threadIdx.x % NTU;
+    const int64_t ul = (int64_t)blockIdx.x * UPW + slot;
+    if (ul >= user_count) return;                                // whole waves only: slot boundaries are wave boundaries
+    unsigned char* smem = smem_all + (size_t)slot * smem_per_user;
+    const int64_t u = a.user_begin + ul;
     const size_t per_user = (size_t)a.m_rx * a.m_tx * a.K;
-    float2* __restrict__ o = out + (size_t)blockIdx.x * per_user;
+    float2* __restrict__ o = out + (size_t)ul * per_user;
     int n_act = ws.n_keep[u] - a.l0;
     n_act = n_act < LPMAX ? n_act : LPMAX;
     if (n_act <= 0) {                                            // channel.py:270-271: stays all-zero
         if (!a.accumulate)
-            for (size_t i = tid; i < per_user; i += 256) o[i] = make_float2(0.f, 0.f);
+            for (size_t i = tid; i < per_user; i += NTU) o[i] = make_float2(0.f, 0.f);
         return;
     }
     const int n4 = (n_act + 3) >> 2;
-    if constexpr (LPMAX >= 32) { if (n4 == 8) { fd_user<32, RB, GLOAD>(ws, a, o, u, n_act, smem); return; } }
-    if constexpr (LPMAX >= 28) { if (n4 == 7) { fd_user<28, RB, GLOAD>(ws, a, o, u, n_act, smem); return; } }
-    if constexpr (LPMAX >= 24) { if (n4 == 6) { fd_user<24, RB, GLOAD>(ws, a, o, u, n_act, smem); return; } }
-    if constexpr (LPMAX >= 20) { if (n4 == 5) { fd_user<20, RB, GLOAD>(ws, a, o, u, n_act, smem); return; } }
-    if constexpr (LPMAX >= 16) { if (n4 == 4) { fd_user<16, RB, GLOAD>(ws, a, o, u, n_act, smem); return; } }
-    if constexpr (LPMAX >= 12) { if (n4 == 3) { fd_user<12, RB, GLOAD>(ws, a, o, u, n_act, smem); return; } }
-    if constexpr (LPMAX >= 8) { if (n4 == 2) { fd_user<8, RB, GLOAD>(ws, a, o, u, n_act, smem); return; } }
-    fd_user<4, RB, GLOAD>(ws, a, o, u, n_act, smem);
+    if constexpr (LPMAX >= 32) { if (n4 == 8) { fd_user<32, RB, GLOAD, WPU>(ws, a, o, u, ul, n_act, smem); return; } }
+    if constexpr (LPMAX >= 28) { if (n4 == 7) { fd_user<28, RB, GLOAD, WPU>(ws, a, o, u, ul, n_act, smem); return; } }
+    if constexpr (LPMAX >= 24) { if (n4 == 6) { fd_user<24, RB, GLOAD, WPU>(ws, a, o, u, ul, n_act, smem); return; } }
+    if constexpr (LPMAX >= 20) { if (n4 == 5) { fd_user<20, RB, GLOAD, WPU>(ws, a, o, u, ul, n_act, smem); return; } }
+    if constexpr (LPMAX >= 16) { if (n4 == 4) { fd_user<16, RB, GLOAD, WPU>(ws, a, o, u, ul, n_act, smem); return; } }
+    if constexpr (LPMAX >= 12) { if (n4 == 3) { fd_user<12, RB, GLOAD, WPU>(ws, a, o, u, ul, n_act, smem); return; } }
+    if constexpr (LPMAX >= 8) { if (n4 == 2) { fd_user<8, RB, GLOAD, WPU>(ws, a, o, u, ul, n_act, smem); return; } }
+    fd_user<4, RB, GLOAD, WPU>(ws, a, o, u, ul, n_act, smem);
 }
 
-template <int LP, int RB, bool GLOAD = false>
-static int launch_valu(const WsView& ws, const FdArgs& a0, int64_t user_count, float2* out, hipStream_t stream) {
-    FdArgs a = a0;
+template <int LP, int RB, bool GLOAD, int WPU>
+static int launch_valu_w(const WsView& ws, FdArgs a, int64_t user_count, float2* out, hipStream_t stream) {
+    constexpr int UPW = 4 / WPU;
     const size_t fixed = (size_t)LP * 8 + (size_t)a.m_rx * 2 * LP * 4;
-    const size_t budget = 64 * 1024;
+    const size_t budget = (64 * 1024) / UPW;                     // LDS share of one user
     if (fixed + (size_t)2 * LP * 4 > budget) {
         set_error("UE array of %d elements does not fit the LDS tables (max about %d)", a.m_rx, (int)(budget / (8 * LP)) - 2);
         return DMX_ERR_SHAPE;
@@ -187,11 +208,23 @@ static int launch_valu(const WsView& ws, const FdArgs& a0, int64_t user_count, f
     int txt = (int)((budget - fixed) / ((size_t)2 * LP * 4));
     if (txt > a.m_tx) txt = a.m_tx;
     a.txt = txt;
-    const size_t smem = fixed + (size_t)txt * 2 * LP * 4;
-    hipLaunchKernelGGL((k2_fd_valu<LP, RB, GLOAD>), dim3((unsigned)user_count), dim3(256), smem, stream, ws, a, out);
+    const size_t per_user = align_up(fixed + (size_t)txt * 2 * LP * 4, 16);
+    const int64_t blocks = (user_count + UPW - 1) / UPW;
+    hipLaunchKernelGGL((k2_fd_valu<LP, RB, GLOAD, WPU>), dim3((unsigned)blocks), dim3(256), per_user * UPW, stream, ws, a, out,
+                       user_count, (int)per_user);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("k2_fd_valu launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
     return DMX_OK;
+}
+
+template <int LP, int RB, bool GLOAD = false>
+static int launch_valu(const WsView& ws, const FdArgs& a, int64_t user_count, float2* out, hipStream_t stream) {
+    // one wave per user when all subcarriers fit one 64-lane chunk and the panel is tiny (measured, 200k users,
+    // 25 paths: 8 pairs x 64 subcarriers 1.89 -> 1.33 ms; from 16 pairs on the four-wave form is as fast or faster)
+    const size_t need = (size_t)LP * 8 + (size_t)(a.m_rx + a.m_tx) * 2 * LP * 4;
+    if (a.K <= 64 && a.m_rx * a.m_tx <= 8 && need <= 16 * 1024 - 16)
+        return launch_valu_w<LP, RB, GLOAD, 1>(ws, a, user_count, out, stream);
+    return launch_valu_w<LP, RB, GLOAD, 4>(ws, a, user_count, out, stream);
 }
 
 static int launch_fd_valu_any(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
