@@ -223,3 +223,39 @@ def test_p2m_parser_matches_reference_parser(tmp_path):
     from deepmimo_amd._native import NativeError
     with pytest.raises(NativeError):
         paths_parser(str(bad))
+
+
+def test_mat5_parser_under_address_sanitizer(tmp_path):
+    """MAT-v5 locator under ASan/UBSan on an intact file, truncated prefixes and clobbered header bytes."""
+    import subprocess
+    import scipy.io
+    a = np.random.default_rng(0).uniform(size=(50, 25)).astype(np.float32)
+    mat = tmp_path / "power.mat"
+    scipy.io.savemat(str(mat), {"power": a})
+    exe = tmp_path / "mat5_asan"
+    cmd = ["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+           os.path.join(ROOT, "deepmimo_amd", "csrc", "mat5_parser.cpp"),
+           os.path.join(ROOT, "tests", "native", "mat5_asan_harness.cpp"), "-o", str(exe)]
+    b = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert b.returncode == 0, b.stdout[-3000:]
+    r = subprocess.run([str(exe), str(mat), "power"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300,
+                       env=dict(os.environ, UBSAN_OPTIONS="halt_on_error=1"))
+    assert r.returncode == 0 and "mat5 asan harness ok" in r.stdout, r.stdout[-3000:]
+
+
+def test_p2m_parser_under_address_sanitizer(tmp_path):
+    """Host-side C++ (text parser) built with -fsanitize=address,undefined and run on the golden file, on
+    truncated prefixes and on corrupted copies: malformed input must fail cleanly, never touch memory out of bounds."""
+    import subprocess
+    z = np.load(os.path.join(ROOT, "tests", "golden", "p2m_paths.npz"), allow_pickle=False)
+    src = tmp_path / "golden.p2m"
+    src.write_text(str(z["p2m_text"]))
+    exe = tmp_path / "p2m_asan"
+    cmd = ["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+           os.path.join(ROOT, "deepmimo_amd", "csrc", "p2m_parser.cpp"),
+           os.path.join(ROOT, "tests", "native", "p2m_asan_harness.cpp"), "-o", str(exe)]
+    b = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert b.returncode == 0, b.stdout[-3000:]
+    r = subprocess.run([str(exe), str(src)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1"))
+    assert r.returncode == 0 and "p2m asan harness ok" in r.stdout, r.stdout[-3000:]
