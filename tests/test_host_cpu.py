@@ -259,3 +259,57 @@ def test_p2m_parser_under_address_sanitizer(tmp_path):
     r = subprocess.run([str(exe), str(src)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1"))
     assert r.returncode == 0 and "p2m asan harness ok" in r.stdout, r.stdout[-3000:]
+
+
+def test_c_abi_argument_validation_without_gpu():
+    """Every entry point rejects malformed arguments with a status code and a message before it touches the GPU
+    (error convention of include/deepmimo_amd.h); runs on the CPU-only container."""
+    import ctypes as C
+    from deepmimo_amd import _native as n
+    lib = n.load()
+
+    def err():
+        return lib.dmx_last_error().decode()
+
+    p = n.DmxParams()
+    p.bs_shape[0], p.bs_shape[1], p.ue_shape[0], p.ue_shape[1] = 8, 1, 1, 1
+    p.num_paths, p.freq_domain, p.n_subcarriers, p.n_selected, p.bandwidth = 5, 1, 64, 0, 10e6
+    r = n.DmxRays()
+    r.n_ue, r.n_paths, r.ld = 4, 5, 5
+    buf = (C.c_char * 65536)()
+    base = (C.addressof(buf) + 255) // 256 * 256
+    assert lib.dmx_path_prep(None, C.byref(p), None, 0, None, None) == -1 and "rays is NULL" in err()
+    assert lib.dmx_path_prep(C.byref(r), None, None, 0, None, None) == -1 and "params is NULL" in err()
+    r.ld = 3
+    assert lib.dmx_path_prep(C.byref(r), C.byref(p), None, 0, None, None) == -1 and "shape" in err()
+    r.ld = 5
+    assert lib.dmx_path_prep(C.byref(r), C.byref(p), None, 0, None, None) == -1 and "ray field pointer is NULL" in err()
+    for k in ("power", "phase", "delay", "aoa_az", "aoa_el", "aod_az", "aod_el", "inter"):
+        setattr(r, k, base)                        # plausible (host) pointers: validation must stop before any launch
+    assert lib.dmx_path_prep(C.byref(r), C.byref(p), None, 0, None, None) == -4 and "workspace too small" in err()
+    need = lib.dmx_workspace_bytes(C.byref(p), 4, 5)
+    assert lib.dmx_path_prep(C.byref(r), C.byref(p), C.c_void_p(base + 8), need, None, None) == -4 and "aligned" in err()
+    p.bs_pattern = 7
+    assert lib.dmx_path_prep(C.byref(r), C.byref(p), C.c_void_p(base), need, None, None) == -1 and "pattern" in err()
+    p.bs_pattern = 0
+    p.bs_shape[0] = 0
+    assert lib.dmx_path_prep(C.byref(r), C.byref(p), C.c_void_p(base), need, None, None) == -2
+    p.bs_shape[0] = 8
+    p.bandwidth = 0.0
+    assert lib.dmx_channels_fd(C.byref(p), C.c_void_p(base), 4, 5, 0, 4, C.c_void_p(base), 0, None) == -1 and "bandwidth" in err()
+    p.bandwidth = 10e6
+    assert lib.dmx_channels_fd(C.byref(p), C.c_void_p(base), 4, 5, 2, 4, C.c_void_p(base), 0, None) == -1 and "user range" in err()
+    assert lib.dmx_channels_fd(C.byref(p), C.c_void_p(base), 4, 5, 0, 4, C.c_void_p(base), 9, None) == -1 and "variant" in err()
+    assert lib.dmx_channels_td(C.byref(p), C.c_void_p(base), 4, 5, 0, 4, C.c_void_p(base), None) == -1 and "freq_domain" in err()
+    p.rx_filter = 1
+    assert lib.dmx_channels_fd(C.byref(p), C.c_void_p(base), 4, 5, 0, 4, C.c_void_p(base), 0, None) == -1
+    p.n_selected = 4
+    p.selected_subcarriers = base
+    assert lib.dmx_channels_fd_lpf(C.byref(p), C.c_void_p(base), 4, 5, 0, 4, None, 0, C.c_void_p(base), None) == -4
+    assert lib.dmx_channels_fd_beams(C.byref(p), C.c_void_p(base), 4, 5, 0, 4, None, 3, None, 0, C.c_void_p(base), None) == -1
+    assert lib.dmx_pathloss(None, 1, None, None) == -1
+    assert lib.dmx_mat_to_rowmajor_f32(None, 99, 4, 4, None, 4, 4, None, None) == -1 and "data type" in err()
+    assert lib.dmx_p2m_count_rx(None, 0) == -1
+    # zero users: every stage is a no-op success
+    r.n_ue = 0
+    assert lib.dmx_path_prep(C.byref(r), C.byref(p), C.c_void_p(base), 4096, None, None) == 0
