@@ -8,7 +8,9 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdeepmimo_amd.so")
+# DMX_LIB_PATH lets a measurement load another build of the same ABI (A/B of two libraries); default = in-tree
+LIB_PATH = os.environ.get("DMX_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                                                          "libdeepmimo_amd.so")
 ABI_VERSION = 1
 
 EXPORTED_SYMBOLS = ("dmx_version", "dmx_last_error", "dmx_workspace_bytes", "dmx_decode_max_delay",
