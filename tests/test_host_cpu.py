@@ -313,3 +313,44 @@ def test_c_abi_argument_validation_without_gpu():
     # zero users: every stage is a no-op success
     r.n_ue = 0
     assert lib.dmx_path_prep(C.byref(r), C.byref(p), C.c_void_p(base), 4096, None, None) == 0
+
+
+def test_reference_patch_installs_on_the_real_reference():
+    """deepmimo_amd.reference_patch.install(dm) on the REAL reference package (build container only: skipped where
+    /root/reference is absent, e.g. on the GPU box).  With use_gpu off the reference's own path runs untouched; with
+    it on and no GPU visible the call fails loudly instead of silently computing on the CPU."""
+    import io
+    import sys
+    from contextlib import redirect_stdout, redirect_stderr
+    if not os.path.isdir("/root/reference/deepmimo"):
+        pytest.skip("reference not present")
+    import torch
+    sys.path.insert(0, "/root/reference")
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    sys.dont_write_bytecode = True
+    try:
+        import deepmimo as dm
+    finally:
+        sys.path.remove("/root/reference")
+    import deepmimo_amd.reference_patch as gpu
+    from oracle import oracle_np as onp
+    rays = onp.synth_rays(12, 5, seed=3)
+    before = dm.Dataset.compute_channels
+    gpu.install(dm)
+    gpu.install(dm)                                                  # idempotent
+    assert dm.Dataset.compute_channels is not before and dm.Dataset.compute_channels._mi355x
+    ds = dm.Dataset({k: v.copy() for k, v in rays.items()})
+    with redirect_stdout(io.StringIO()), redirect_stderr(io.StringIO()):
+        dm.config("use_gpu", False)
+        H = ds.compute_channels(dm.ChannelGenParameters())
+    ref = onp.compute_channels(rays, onp.make_params())
+    assert np.array_equal(H, ref["channel"])
+    if not torch.cuda.is_available():
+        with redirect_stdout(io.StringIO()):
+            dm.config("use_gpu", True)
+        try:
+            with pytest.raises(RuntimeError, match="no GPU"):
+                ds.compute_channels(dm.ChannelGenParameters())
+        finally:
+            with redirect_stdout(io.StringIO()):
+                dm.config("use_gpu", False)
