@@ -534,3 +534,25 @@ def test_hip_graph_replay():
     assert np.array_equal(prep.side["los"].cpu().numpy(), onp.compute_channels(b, onp.make_params(
         bs_antenna=dict(shape=[8, 4]), ue_antenna=dict(shape=[2, 1]),
         ofdm=dict(selected_subcarriers=np.arange(0, 512, 8))))["los"])
+
+
+def test_reference_patch_gpu_path():
+    """The body reference_patch installs into the reference's Dataset (the real package cannot travel to the GPU
+    box): run it here on a Dataset-shaped object and compare with the goldens of the real reference."""
+    import deepmimo_amd as dm
+    from deepmimo_amd import reference_patch as rp
+    case, rays, ue_rot, ref = load_golden("g03_rot_fov")
+    ds = _dataset(case, rays)
+    p = _dm_params(case, ue_rot)
+    ds.set_channel_params(p)
+    np.random.seed(1001)
+    H = rp._gpu_compute_channels(ds, p, 0)
+    assert_channel_close(H, ref["channel"], what="reference_patch body")
+    np.testing.assert_array_equal(ds["los"], ref["los"])
+    np.testing.assert_array_equal(ds["_fov_mask"], ref["fov_mask"])
+    case, rays, ue_rot, ref = load_golden("g09_random_ue_rot")       # random UE-rotation range: same RNG order
+    ds = _dataset(case, rays)
+    p = _dm_params(case, ue_rot)
+    ds.set_channel_params(p)
+    np.random.seed(1001)
+    assert_channel_close(rp._gpu_compute_channels(ds, p, 0), ref["channel"], what="reference_patch random rotation")
