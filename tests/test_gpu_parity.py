@@ -556,3 +556,52 @@ def test_reference_patch_gpu_path():
     ds.set_channel_params(p)
     np.random.seed(1001)
     assert_channel_close(rp._gpu_compute_channels(ds, p, 0), ref["channel"], what="reference_patch random rotation")
+
+
+def test_c_abi_demo_client_matches_python_host():
+    """examples/c_abi_demo.cpp: a C++ program with hipMalloc'ed buffers and plain structs - no Python, no PyTorch -
+    calling the C-ABI.  Its inputs come from a fixed LCG; the same inputs through the Python host must give the same
+    tensor fingerprints, LoS and path-count sums."""
+    import json
+    import subprocess
+    import deepmimo_amd as dm
+    from deepmimo_amd._native import LIB_PATH
+    exe = os.path.join(os.path.dirname(LIB_PATH), "dmx_demo")
+    if not os.path.exists(exe):
+        pytest.skip("demo client not built (make -C deepmimo_amd/csrc)")
+    n, L, K = 2000, 10, 64
+    r = subprocess.run([exe, str(n)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["abi"] == 1 and got["shape"] == [n, 2, 16, K]
+    # the demo's LCG, vectorised: s_{i+1} = a s_i + c (mod 2^32)
+    total = 8 * n * L
+    state = np.empty(total, dtype=np.uint64)
+    s_ = 12345
+    for i in range(total):
+        s_ = (s_ * 1664525 + 1013904223) & 0xFFFFFFFF
+        state[i] = s_
+    x = (state >> np.uint64(8)).astype(np.float32)
+    lo = np.array([-140, -180, 1e-8, -180, 0, -180, 0, 0], dtype=np.float32)
+    hi = np.array([-60, 180, 2e-6, 180, 180, 180, 180, 4.999], dtype=np.float32)
+    keys = ("power", "phase", "delay", "aoa_az", "aoa_el", "aod_az", "aod_el", "inter")
+    rays = {}
+    for f, k in enumerate(keys):
+        t = ((hi[f] - lo[f]) * x[f * n * L:(f + 1) * n * L]).astype(np.float32) * np.float32(1.0 / 16777216.0)
+        rays[k] = (lo[f] + t.astype(np.float32)).astype(np.float32).reshape(n, L)
+    rays["inter"] = np.floor(rays["inter"])
+    for k in keys:
+        rays[k][::7, 3:] = np.nan
+    rays["rx_pos"] = np.zeros((n, 3), np.float32)
+    rays["tx_pos"] = np.zeros((1, 3), np.float32)
+    p = dm.ChannelGenParameters()
+    p.bs_antenna.shape, p.ue_antenna.shape = np.array([8, 2]), np.array([2, 1])
+    p.bs_antenna.rotation = np.array([0, 0, 30])
+    p.ofdm.selected_subcarriers = np.arange(K)
+    ds = dm.Dataset(rays)
+    H = ds.compute_channels(p)
+    h = np.ascontiguousarray(H).view(np.float32).astype(np.float64).ravel()
+    energy, wsum = float(np.sum(h * h)), float(np.sum(h * np.cos(0.37 * np.arange(h.size, dtype=np.float64))))
+    assert got["energy"] == pytest.approx(energy, rel=1e-9)
+    assert got["wsum"] == pytest.approx(wsum, rel=1e-6, abs=1e-9 * np.sqrt(energy))
+    assert got["los_sum"] == int(ds.los.sum()) and got["num_paths_sum"] == int(ds.num_paths.sum())
