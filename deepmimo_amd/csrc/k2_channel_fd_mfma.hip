@@ -56,6 +56,7 @@ struct MfmaArgs {
     const int32_t* fexp;     // [user_count]              exponent of max |f| per user
     // rx_filter variant: per-path subcarrier gains precomputed by k3_lpf_* instead of generated here
     const float2* gtab;      // [user_count, P, K] or nullptr
+    int factored;            // build A' from the a_rx / a_tx factor tables (they fit the lo-tile region)
 };
 
 // (x0, x1) -> packed hi pair and packed lo pair, x = hi + lo.  v_cvt_pkrtz_f16_f32 converts two floats per
@@ -126,9 +127,9 @@ __device__ __forceinline__ void gen_b_fragments(int strip, int col, int hh, size
 // workgroup mean more waves in flight per CU (LDS, not registers, limits occupancy here: 74 KB per
 // workgroup -> 2 workgroups per CU).  Measured at the headline config: 19.4 / 19.0 / 18.4 ms for 4 / 8 / 16.
 template <bool NT, int NW, int SPW>
-__global__ __launch_bounds__(NW * 64) void k2_fd_mfma(WsView ws, MfmaArgs a, float* __restrict__ out) {
+__device__ __forceinline__ void mfma_block(const WsView& ws, const MfmaArgs& a, float* __restrict__ out, int64_t work,
+                                           unsigned char* smem) {
     constexpr int NTHR = NW * 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Ahi = smem;                                          // [rows][144 B]
     unsigned char* Alo = smem + (size_t)a.rows * ROW_BYTES;
     double* qtab = reinterpret_cast<double*>(smem + (size_t)2 * a.rows * ROW_BYTES);   // [32] dn_l / N
@@ -137,8 +138,8 @@ __global__ __launch_bounds__(NW * 64) void k2_fd_mfma(WsView ws, MfmaArgs a, flo
     float* misc = citab + LPAD;                                         // [4] per-user output scale
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t ul = blockIdx.x / a.nblk;
-    const int blk = blockIdx.x % a.nblk;
+    const int64_t ul = work / a.nblk;
+    const int blk = (int)(work % a.nblk);
     const int64_t u = a.user_begin + ul;
     const int row0 = blk * MAX_ROWS;
     const int nrows = (a.M - row0) < MAX_ROWS ? (a.M - row0) : MAX_ROWS;   // valid rows of this block
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(NW * 64) void k2_fd_mfma(WsView ws, MfmaArgs a, flo
                     rhi[l] = vh;
                     rlo[l] = vl;
                 }
-            } else {
+            } else if (!a.factored) {
                 for (int l = l0; l < l0 + LPER; ++l) {
                     h2 vh = {(_Float16)0.f, (_Float16)0.f}, vl = vh;
                     if (pok && l < n_act) {
@@ -216,6 +217,50 @@ __global__ __launch_bounds__(NW * 64) void k2_fd_mfma(WsView ws, MfmaArgs a, flo
                     rlo[l] = vl;
                 }
             }
+        }
+    }
+    if (!a.n_beams && a.factored) {
+        // Factored form: A[(rx,tx), l] = a_rx[rx,l] * a_tx[tx,l], so only (M_rx + M_tx) * L phases need a sin/cos
+        // instead of M_rx * M_tx * L.  The two factor tables (float2 [M_rx + M_tx][32]) live in the region that will
+        // hold the lo tiles: T1 tables -> barrier -> T2 products (hi tiles to LDS, lo halves kept in registers)
+        // -> barrier -> T3 lo tiles.
+        float2* tab = reinterpret_cast<float2*>(Alo);              // [m_rx][32] then [m_tx][32]
+        for (int i = tid; i < (a.m_rx + a.m_tx) * LPAD; i += NTHR) {
+            const int e = i >> 5, l = i & 31;
+            float s = 0.f, c = 0.f;
+            if (l < n_act) {
+                if (e < a.m_rx) sincos_rev(frac_rev((double)(e % a.ue_mh) * ws.rx_y[rb + l] + (double)(e / a.ue_mh) * ws.rx_z[rb + l]), s, c);
+                else { const int t = e - a.m_rx; sincos_rev(frac_rev((double)(t % a.bs_mh) * ws.tx_y[rb + l] + (double)(t / a.bs_mh) * ws.tx_z[rb + l]), s, c); }
+            }
+            tab[i] = make_float2(c, s);
+        }
+        __syncthreads();
+        const int r = tid & 255, l0 = (tid >> 8) * LPER;
+        const int p = row0 + r;
+        const bool rok = r < a.rows, pok = rok && p < a.M;
+        const int rx = pok ? p / a.m_tx : 0, tx = pok ? p - rx * a.m_tx : 0;
+        h2 lo_keep[LPER];
+        if (rok) {
+            h2* rhi = reinterpret_cast<h2*>(Ahi + (size_t)r * ROW_BYTES);
+            const float2* trx = tab + (size_t)rx * LPAD;
+            const float2* ttx = tab + (size_t)(a.m_rx + tx) * LPAD;
+#pragma unroll
+            for (int j = 0; j < LPER; ++j) {
+                const int l = l0 + j;
+                h2 vh = {(_Float16)0.f, (_Float16)0.f};
+                lo_keep[j] = vh;
+                if (pok && l < n_act) {
+                    const float2 u1 = trx[l], u2 = ttx[l];
+                    split2_f16((u1.x * u2.x - u1.y * u2.y) * A_SCALE, (u1.x * u2.y + u1.y * u2.x) * A_SCALE, vh, lo_keep[j]);
+                }
+                rhi[l] = vh;
+            }
+        }
+        __syncthreads();                                            // every table read is done: the region becomes Alo
+        if (rok) {
+            h2* rlo = reinterpret_cast<h2*>(Alo + (size_t)r * ROW_BYTES);
+#pragma unroll
+            for (int j = 0; j < LPER; ++j) rlo[l0 + j] = lo_keep[j];
         }
     }
     __syncthreads();
@@ -276,6 +321,18 @@ __global__ __launch_bounds__(NW * 64) void k2_fd_mfma(WsView ws, MfmaArgs a, flo
                 }
             }
         }
+    }
+}
+
+// One (user, row block) per loop iteration.  Launched with one workgroup per work item, or persistently (grid =
+// what is resident at once, workgroups stride over the work items): every phase is workgroup-uniform, so the only
+// extra synchronisation is the barrier that keeps the next item's A' tiles from overwriting the current ones.
+template <bool NT, int NW, int SPW>
+__global__ __launch_bounds__(NW * 64) void k2_fd_mfma(WsView ws, MfmaArgs a, float* __restrict__ out, int64_t total) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
+        mfma_block<NT, NW, SPW>(ws, a, out, w, smem);
+        __syncthreads();
     }
 }
 
@@ -468,13 +525,22 @@ bool fd_mfma_preferred(const dmx_params& prm, const WsView& ws) {
 }
 
 template <bool NT, int NW, int SPW>
-static int launch_mfma_t(const WsView& ws, const MfmaArgs& a, int64_t blocks, size_t smem, float2* out, hipStream_t stream) {
+static int launch_mfma_t(const WsView& ws, const MfmaArgs& a, int64_t blocks, size_t smem, float2* out, hipStream_t stream,
+                         bool persistent = true) {
     const void* kfn = reinterpret_cast<const void*>(k2_fd_mfma<NT, NW, SPW>);
     if (smem > 64 * 1024) {     // per device and cheap: no cached flag, so every GPU of a process gets it
         hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MAX_ROWS * ROW_BYTES + 1024);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
     }
-    hipLaunchKernelGGL((k2_fd_mfma<NT, NW, SPW>), dim3((unsigned)blocks), dim3(NW * 64), smem, stream, ws, a, reinterpret_cast<float*>(out));
+    int64_t grid = blocks;
+    if (persistent) {                                           // workgroups resident at once on 256 CUs (32 waves per CU)
+        int per_cu = 32 / NW;
+        const int by_lds = (int)((size_t)160 * 1024 / (smem ? smem : 1));
+        if (by_lds < per_cu) per_cu = by_lds > 0 ? by_lds : 1;
+        const int64_t resident = (int64_t)256 * per_cu;
+        if (grid > resident) grid = resident;
+    }
+    hipLaunchKernelGGL((k2_fd_mfma<NT, NW, SPW>), dim3((unsigned)grid), dim3(NW * 64), smem, stream, ws, a, reinterpret_cast<float*>(out), blocks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("k2_fd_mfma launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
     return DMX_OK;
@@ -548,6 +614,9 @@ static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user
     a.nblk = (a.M + MAX_ROWS - 1) / MAX_ROWS;
     const int mrows = a.M < MAX_ROWS ? a.M : MAX_ROWS;
     a.rows = (mrows + 31) / 32 * 32;
+    // factor tables need (M_rx + M_tx) * 32 * 8 B inside the lo-tile region and pay off when they replace more
+    // sin/cos than they cost
+    a.factored = !n_beams && (size_t)(a.m_rx + a.m_tx) * LPAD * 8 <= (size_t)a.rows * ROW_BYTES && (a.m_rx + a.m_tx) * 2 <= a.M;
     const size_t smem = (size_t)2 * a.rows * ROW_BYTES + LPAD * (8 + 4 + 4) + 16;
     const int64_t blocks = user_count * a.nblk;
     if (blocks > 0x7fffffffLL) { set_error("too many workgroups for one call"); return DMX_ERR_SHAPE; }
@@ -561,6 +630,7 @@ static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user
         case 3: return launch_mfma_t<true, 8, 1>(ws, a, blocks, smem, out, stream);
         case 4: return launch_mfma_t<true, 8, 2>(ws, a, blocks, smem, out, stream);
         case 5: return launch_mfma_t<true, 16, 2>(ws, a, blocks, smem, out, stream);
+        case 6: return launch_mfma_t<true, 16, 1>(ws, a, blocks, smem, out, stream, false);     // one workgroup per work item
         default: return launch_mfma_t<true, 16, 1>(ws, a, blocks, smem, out, stream);
     }
 }
