@@ -102,7 +102,35 @@ def cpu_baseline_here(w, sample_users, workers):
             dtw = time.perf_counter() - t0
         out["all_cores"] = {"value": per * workers / dtw, "unit": "user-channels/s", "cores": workers,
                             "sample": f"{workers} processes x {per} users, {dtw:.1f} s wall"}
+    out["c_port"] = c_port_baseline(w, sample_users, workers)
     return out
+
+
+def c_port_baseline(w, sample_users, workers):
+    """The oracle's plain-C restatement (oracle/oracle_c.c: scalar loops, complex128 accumulation) on the same
+    sample: one thread, then `workers` OpenMP threads over users.  Reported beside the NumPy figure because a
+    compiled port is what a CPU deployment of this path would look like; `value` above stays the reference's own
+    execution model."""
+    from oracle import oracle_np as onp, oracle_c as oc
+    op = onp.make_params(bs_antenna=dict(shape=w["bs"]), ue_antenna=dict(shape=w["ue"]), num_paths=w["L"],
+                         ofdm=dict(subcarriers=w["N"], selected_subcarriers=np.arange(w["N"])))
+
+    def run(n, threads, seed):
+        rays = onp.synth_rays(n, w["L"], seed=seed, all_valid=True)
+        t0 = time.perf_counter()
+        oc.compute_channels(rays, op, threads=threads)
+        return time.perf_counter() - t0
+
+    run(max(1, min(16, sample_users // 8)), 1, 98)
+    dt1 = min(run(sample_users, 1, 4321) for _ in range(2))
+    res = {"value": sample_users / dt1, "unit": "user-channels/s", "cores": 1, "kind": "port",
+           "sample": f"{sample_users} users, oracle/oracle_c.c, 1 thread, best of 2: {dt1:.1f} s"}
+    if workers > 1:
+        n = sample_users * min(workers, 8)
+        dtw = min(run(n, workers, 777) for _ in range(2))
+        res["all_cores"] = {"value": n / dtw, "unit": "user-channels/s", "cores": workers,
+                            "sample": f"{n} users, {workers} OpenMP threads, best of 2: {dtw:.1f} s"}
+    return res
 
 
 def cpu_baseline(workload, users_override, sample_users, workers):

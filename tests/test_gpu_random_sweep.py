@@ -5,58 +5,16 @@ golden vectors).  Tolerance 5e-5 of each user's peak; LoS / path counts / FoV ma
 import numpy as np
 import pytest
 
-from tests._cases import assert_channel_close
+from tests._cases import assert_channel_close, random_case
 
 pytestmark = pytest.mark.gpu
-
-
-def _random_config(rng):
-    bs = [int(rng.integers(1, 13)), int(rng.integers(1, 9))]
-    ue = [int(rng.integers(1, 4)), int(rng.integers(1, 4))]
-    L = int(rng.integers(1, 33))
-    N = int(rng.choice([16, 48, 64, 100, 256, 512]))
-    K = int(rng.integers(1, min(N, 96) + 1))
-    sel = np.sort(rng.choice(N, size=K, replace=False)) if rng.uniform() < 0.7 else rng.integers(0, N, K)
-    mode = rng.choice(["fd", "fd", "fd", "td", "lpf"])
-    cfg = dict(bs=bs, ue=ue, L=L, N=N, sel=sel, mode=mode,
-               n_ue=int(rng.integers(1, 90)),
-               num_paths=int(rng.integers(1, L + 6)),
-               bs_rot=rng.integers(-180, 181, 3) if rng.uniform() < 0.6 else np.zeros(3, int),
-               ue_rot_mode=rng.choice(["zero", "const", "per_user"]),
-               bs_fov=[int(rng.integers(30, 361)), int(rng.integers(20, 181))] if rng.uniform() < 0.5 else None,
-               ue_fov=[int(rng.integers(30, 361)), int(rng.integers(20, 181))] if rng.uniform() < 0.3 else None,
-               bs_pat=rng.choice(["isotropic", "halfwave-dipole"], p=[0.7, 0.3]),
-               ue_pat=rng.choice(["isotropic", "halfwave-dipole"], p=[0.8, 0.2]),
-               spacing=float(rng.choice([0.5, 0.25, 0.7])),
-               bandwidth=float(rng.choice([10e6, 20e6, 100e6])),
-               max_delay=float(rng.choice([5e-7, 2e-6, 2e-5])),
-               holes=rng.uniform() < 0.3)
-    if mode == "lpf":
-        cfg["N"] = int(rng.choice([16, 48, 64]))
-        cfg["sel"] = np.arange(0, cfg["N"], int(rng.integers(1, 4)))
-    return cfg
 
 
 @pytest.mark.parametrize("seed", range(120))
 def test_random_configuration(seed):
     import deepmimo_amd as dm
     from oracle import oracle_np as onp
-    rng = np.random.default_rng(9000 + seed)
-    c = _random_config(rng)
-    n = c["n_ue"]
-    rays = onp.synth_rays(n, c["L"], seed=seed, max_delay=c["max_delay"])
-    if c["holes"]:
-        hole = rng.uniform(size=(n, c["L"])) < 0.2
-        for k in onp.RAY_KEYS:
-            rays[k][hole] = np.nan
-    if c["ue_rot_mode"] == "zero":
-        ue_rot = np.zeros(3, int)
-    elif c["ue_rot_mode"] == "const":
-        ue_rot = rng.integers(-90, 91, 3)
-    else:
-        ue_rot = rng.uniform(-60, 60, (n, 3))
-        if n == 3:                                     # (3, 3) would be ambiguous with nothing; keep it per-user anyway
-            ue_rot = rng.uniform(-60, 60, (n, 3))
+    c, rays, ue_rot, op, bs_fov, ue_fov = random_case(seed)
     fd = c["mode"] != "td"
     p = dm.ChannelGenParameters()
     p.bs_antenna.shape, p.ue_antenna.shape = np.array(c["bs"]), np.array(c["ue"])
@@ -66,15 +24,7 @@ def test_random_configuration(seed):
     p.num_paths, p.freq_domain = c["num_paths"], int(fd)
     p.ofdm.subcarriers, p.ofdm.selected_subcarriers = c["N"], np.asarray(c["sel"])
     p.ofdm.bandwidth, p.ofdm.rx_filter = c["bandwidth"], int(c["mode"] == "lpf")
-    op = onp.make_params(
-        bs_antenna=dict(shape=c["bs"], spacing=c["spacing"], rotation=np.array(c["bs_rot"]), radiation_pattern=str(c["bs_pat"])),
-        ue_antenna=dict(shape=c["ue"], spacing=c["spacing"], rotation=np.array(ue_rot), radiation_pattern=str(c["ue_pat"])),
-        num_paths=c["num_paths"], freq_domain=int(fd),
-        ofdm=dict(subcarriers=c["N"], selected_subcarriers=np.asarray(c["sel"]), bandwidth=c["bandwidth"],
-                  rx_filter=int(c["mode"] == "lpf")))
     ds = dm.Dataset(dict(rays))
-    bs_fov = None if c["bs_fov"] is None else np.array(c["bs_fov"])
-    ue_fov = None if c["ue_fov"] is None else np.array(c["ue_fov"])
     if bs_fov is not None or ue_fov is not None:
         kw = {}
         if bs_fov is not None:
