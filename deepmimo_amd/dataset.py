@@ -40,6 +40,16 @@ _UE_ROT_RESOLVED = "_ue_rotation_resolved"     # [n_ue, 3] degrees actually used
 _engines: Dict[int, Any] = {}
 
 
+class _DeviceSide:
+    """Placeholder of a stage-1 side product that is still in HBM.  It sits in the Dataset's dict under the
+    product's key (so ``in`` / ``keys()`` behave as in the reference, where the array is cached eagerly) and is
+    replaced by the NumPy array the reference would hold the first time anything reads it."""
+    __slots__ = ("make",)
+
+    def __init__(self, make):
+        self.make = make
+
+
 def _engine():
     """Process-wide ChannelEngine for config('gpu_device_id').  Raises when use_gpu is off."""
     if not config.get("use_gpu", True):
@@ -58,31 +68,66 @@ class Dataset(DotDict):
         super().__init__(data or {})
 
     # -------------------------------------------------------------- lookup chain (dataset.py:130-182)
+    def _host(self, key: str) -> Any:
+        """self._data[key], copied out of HBM first if it is still a device-side placeholder."""
+        v = self._data[key]
+        if isinstance(v, _DeviceSide):
+            v = v.make()
+            self._data[key] = v
+        return v
+
+    def _host_all(self) -> None:
+        for k in [k for k, v in self._data.items() if isinstance(v, _DeviceSide)]:
+            self._host(k)
+
     def __getattr__(self, key: str) -> Any:
         if key.startswith("__"):
             raise AttributeError(key)
         try:
-            return self._data[key]
+            return self._host(key)
         except KeyError:
             return self._resolve_key(key)
 
     def __getitem__(self, key: str) -> Any:
         try:
-            return self._data[key]
+            return self._host(key)
         except KeyError:
             return self._resolve_key(key)
+
+    def get(self, key: str, default: Any = None) -> Any:
+        return self._host(key) if key in self._data else default
+
+    def values(self):
+        self._host_all()
+        return self._data.values()
+
+    def items(self):
+        self._host_all()
+        return self._data.items()
+
+    def to_dict(self) -> Dict:
+        self._host_all()
+        return super().to_dict()
+
+    def deepcopy(self):
+        self._host_all()
+        return super().deepcopy()
+
+    def __repr__(self) -> str:
+        self._host_all()
+        return super().__repr__()
 
     def _resolve_key(self, key: str) -> Any:
         resolved = c.DATASET_ALIASES.get(key, key)
         if resolved != key:
             key = resolved
             if key in self._data:
-                return self._data[key]
+                return self._host(key)
         if key in self._computed_attributes:
             value = getattr(self, self._computed_attributes[key])()
             if isinstance(value, dict):
                 self.update(value)
-                return self._data[key]
+                return self._host(key)
             self[key] = value
             return value
         raise KeyError(key)
@@ -144,23 +189,34 @@ class Dataset(DotDict):
         return eng, prep
 
     def _store_side(self, prep) -> None:
+        """Register every side product of stage 1 under the reference's cache keys.  The arrays stay in HBM
+        (`_DeviceSide`) until something reads them: at 100k users x 25 paths they are ~120 MB of device-to-host
+        copies that a caller who only wants the channel tensor never pays for."""
         s = prep.side
-        host = {k: (None if v is None else v.cpu().numpy()) for k, v in s.items() if k != "max_delay_key"}
-        mask = None if host["fov_mask"] is None else host["fov_mask"].astype(bool)
-        rot = {c.AOD_EL_ROT_PARAM_NAME: host["aod_el_rot"], c.AOD_AZ_ROT_PARAM_NAME: host["aod_az_rot"],
-               c.AOA_EL_ROT_PARAM_NAME: host["aoa_el_rot"], c.AOA_AZ_ROT_PARAM_NAME: host["aoa_az_rot"]}
+        memo: Dict[str, np.ndarray] = {}
+
+        def host(name):                                   # one D2H copy per product, shared by its dependants
+            if name not in memo:
+                memo[name] = s[name].cpu().numpy()
+            return memo[name]
+
+        has_mask = s["fov_mask"] is not None
         d = self._data
-        d.update(rot)
-        d[c.FOV_MASK_PARAM_NAME] = mask
-        for k_rot, k_fov in zip(_ROT_KEYS, _FOV_ANGLE_KEYS):                  # dataset.py:506-511
-            d[k_fov] = rot[k_rot] if mask is None else np.where(mask, rot[k_rot], np.nan)
-        d[c.PWR_LINEAR_PARAM_NAME] = host["power_linear"]
+        d[c.FOV_MASK_PARAM_NAME] = _DeviceSide(lambda: host("fov_mask").astype(bool)) if has_mask else None
+        for k_rot, k_fov, name in zip(_ROT_KEYS, _FOV_ANGLE_KEYS, ("aod_el_rot", "aod_az_rot", "aoa_el_rot", "aoa_az_rot")):
+            d[k_rot] = _DeviceSide(lambda name=name: host(name))
+            if has_mask:                                                      # dataset.py:506-511
+                d[k_fov] = _DeviceSide(lambda name=name: np.where(host("fov_mask").astype(bool), host(name), np.nan))
+            else:
+                d[k_fov] = _DeviceSide(lambda name=name: host(name))
+        d[c.PWR_LINEAR_PARAM_NAME] = _DeviceSide(lambda: host("power_linear"))
         iso = all(self.ch_params[s_][c.PARAMSET_ANT_RAD_PAT] == c.PARAMSET_ANT_RAD_PAT_VALS[0]
                   for s_ in (c.PARAMSET_ANT_BS, c.PARAMSET_ANT_UE))
-        g = host["power_linear_ant_gain"]
-        d[c.PWR_LINEAR_ANT_GAIN_PARAM_NAME] = g.astype(np.float32) if iso else g   # float32 * 1.0 stays float32
-        d[c.NUM_PATHS_PARAM_NAME] = host["num_paths"].astype(np.int64)
-        d[c.LOS_PARAM_NAME] = host["los"].astype(np.int64)
+        # float32 * 1.0 stays float32 in the reference (ant_patterns.py:167-168)
+        d[c.PWR_LINEAR_ANT_GAIN_PARAM_NAME] = _DeviceSide(
+            lambda: host("power_linear_ant_gain").astype(np.float32) if iso else host("power_linear_ant_gain"))
+        d[c.NUM_PATHS_PARAM_NAME] = _DeviceSide(lambda: host("num_paths").astype(np.int64))
+        d[c.LOS_PARAM_NAME] = _DeviceSide(lambda: host("los").astype(np.int64))
 
     def compute_channels(self, params: Optional[ChannelGenParameters] = None):
         """dataset.py:224-268.  Returns complex64 [n_ue, M_rx, M_tx, K] (freq_domain) or
@@ -244,15 +300,15 @@ class Dataset(DotDict):
         if key not in self._data:
             _ = self.ch_params                                              # resolves defaults if never set
             self._run_prep(want_side=True)
-        return self._data[key]
+        return self._host(key)
 
     def _compute_rotated_angles(self) -> Dict[str, np.ndarray]:
         self._side(c.AOD_EL_ROT_PARAM_NAME)
-        return {k: self._data[k] for k in _ROT_KEYS}
+        return {k: self._host(k) for k in _ROT_KEYS}
 
     def _compute_fov(self) -> Dict[str, Any]:
         self._side(c.FOV_MASK_PARAM_NAME)
-        return {k: self._data[k] for k in (c.FOV_MASK_PARAM_NAME,) + _FOV_ANGLE_KEYS}
+        return {k: self._host(k) for k in (c.FOV_MASK_PARAM_NAME,) + _FOV_ANGLE_KEYS}
 
     def _compute_num_paths(self) -> np.ndarray:
         return self._side(c.NUM_PATHS_PARAM_NAME)

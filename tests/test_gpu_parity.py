@@ -220,6 +220,35 @@ def test_cache_semantics_and_aliases():
         ds2["no_such_matrix"]
 
 
+def test_side_products_stay_in_hbm_until_read():
+    """The reference caches los / num_paths / rotated angles / powers as NumPy arrays inside compute_channels; here
+    they are registered under the same keys but copied out of HBM only when read (dataset.py:_DeviceSide)."""
+    import deepmimo_amd as dm
+    from deepmimo_amd.dataset import _DeviceSide
+    from oracle import oracle_np as onp
+    rays = onp.synth_rays(32, 7, seed=21)
+    ds = dm.Dataset(dict(rays))
+    ds.apply_fov(bs_fov=np.array([120, 90]))
+    ds.compute_channels(dm.ChannelGenParameters())
+    side_keys = ("los", "num_paths", "power_linear", "_power_linear_ant_gain", "_fov_mask",
+                 "_aod_el_rot", "_aoa_az_rot", "_aod_el_rot_fov", "_aoa_az_rot_fov")
+    assert all(k in ds.keys() for k in side_keys)
+    assert all(isinstance(ds._data[k], _DeviceSide) for k in side_keys)
+    ref = onp.compute_channels(rays, onp.make_params(), bs_fov=np.array([120, 90]))
+    np.testing.assert_array_equal(ds.los, ref["los"])                       # attribute access
+    assert isinstance(ds._data["los"], np.ndarray) and isinstance(ds._data["num_paths"], _DeviceSide)
+    np.testing.assert_array_equal(ds["n_paths"] if "n_paths" in dm.consts.DATASET_ALIASES else ds["num_paths"],
+                                  ref["num_paths"])                          # item access
+    np.testing.assert_array_equal(ds.get("_fov_mask"), ref["_fov_mask"])    # Mapping.get
+    m = ref["_fov_mask"]
+    np.testing.assert_allclose(ds["_aod_el_rot_fov"], np.where(m, ref["_aod_el_rot"], np.nan), atol=1e-11, equal_nan=True)
+    d = ds.to_dict()                                                         # everything else lands on export
+    assert not any(isinstance(v, _DeviceSide) for v in d.values())
+    assert d["power_linear"].dtype == np.float32 and d["_power_linear_ant_gain"].dtype == np.float32
+    ds.apply_fov()                                                           # invalidation drops placeholders too
+    assert "los" not in ds.keys() and "_fov_mask" not in ds.keys()
+
+
 def test_macro_dataset_fan_out():
     import deepmimo_amd as dm
     from oracle import oracle_np as onp

@@ -10,10 +10,8 @@ from tests._cases import assert_channel_close, random_case
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", range(120))
-def test_random_configuration(seed):
+def _run_hip(seed):
     import deepmimo_amd as dm
-    from oracle import oracle_np as onp
     c, rays, ue_rot, op, bs_fov, ue_fov = random_case(seed)
     fd = c["mode"] != "td"
     p = dm.ChannelGenParameters()
@@ -32,8 +30,11 @@ def test_random_configuration(seed):
         if ue_fov is not None:
             kw["ue_fov"] = ue_fov
         ds.apply_fov(**kw)
-    ref = onp.compute_channels(rays, op, bs_fov=bs_fov, ue_fov=ue_fov)
     H = ds.compute_channels(p)
+    return c, rays, op, bs_fov, ue_fov, ds, H
+
+
+def _check(seed, c, ds, H, ref):
     assert_channel_close(H, ref["channel"], what=f"seed {seed}: {c}")
     np.testing.assert_array_equal(ds.los, ref["los"])
     np.testing.assert_array_equal(ds.num_paths, ref["num_paths"])
@@ -41,3 +42,19 @@ def test_random_configuration(seed):
         assert ds["_fov_mask"] is None
     else:
         np.testing.assert_array_equal(ds["_fov_mask"], ref["_fov_mask"])
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_random_configuration(seed):
+    from oracle import oracle_np as onp
+    c, rays, op, bs_fov, ue_fov, ds, H = _run_hip(seed)
+    _check(seed, c, ds, H, onp.compute_channels(rays, op, bs_fov=bs_fov, ue_fov=ue_fov))
+
+
+@pytest.mark.parametrize("seed", range(200, 230))
+def test_random_configuration_against_c_twins(seed):
+    """Same sweep, checked by the second oracle: dmx_path_prep / dmx_channels_* on the GPU against their CPU twins
+    dmx_cpu_path_prep / dmx_cpu_channels_* (oracle/oracle_c.c) on the same rays and parameters."""
+    from oracle import oracle_c as oc
+    c, rays, op, bs_fov, ue_fov, ds, H = _run_hip(seed)
+    _check(seed, c, ds, H, oc.compute_channels(rays, op, bs_fov=bs_fov, ue_fov=ue_fov, threads=4))
