@@ -56,7 +56,6 @@ struct MfmaArgs {
     const int32_t* fexp;     // [user_count]              exponent of max |f| per user
     // rx_filter variant: per-path subcarrier gains precomputed by k3_lpf_* instead of generated here
     const float2* gtab;      // [user_count, P, K] or nullptr
-    int factored;            // build A' from the a_rx / a_tx factor tables (they fit the lo-tile region)
 };
 
 // (x0, x1) -> packed hi pair and packed lo pair, x = hi + lo.  v_cvt_pkrtz_f16_f32 converts two floats per
@@ -204,7 +203,7 @@ __device__ __forceinline__ void mfma_block(const WsView& ws, const MfmaArgs& a, 
                     rhi[l] = vh;
                     rlo[l] = vl;
                 }
-            } else if (!a.factored) {
+            } else {
                 for (int l = l0; l < l0 + LPER; ++l) {
                     h2 vh = {(_Float16)0.f, (_Float16)0.f}, vl = vh;
                     if (pok && l < n_act) {
@@ -217,50 +216,6 @@ __device__ __forceinline__ void mfma_block(const WsView& ws, const MfmaArgs& a, 
                     rlo[l] = vl;
                 }
             }
-        }
-    }
-    if (!a.n_beams && a.factored) {
-        // Factored form: A[(rx,tx), l] = a_rx[rx,l] * a_tx[tx,l], so only (M_rx + M_tx) * L phases need a sin/cos
-        // instead of M_rx * M_tx * L.  The two factor tables (float2 [M_rx + M_tx][32]) live in the region that will
-        // hold the lo tiles: T1 tables -> barrier -> T2 products (hi tiles to LDS, lo halves kept in registers)
-        // -> barrier -> T3 lo tiles.
-        float2* tab = reinterpret_cast<float2*>(Alo);              // [m_rx][32] then [m_tx][32]
-        for (int i = tid; i < (a.m_rx + a.m_tx) * LPAD; i += NTHR) {
-            const int e = i >> 5, l = i & 31;
-            float s = 0.f, c = 0.f;
-            if (l < n_act) {
-                if (e < a.m_rx) sincos_rev(frac_rev((double)(e % a.ue_mh) * ws.rx_y[rb + l] + (double)(e / a.ue_mh) * ws.rx_z[rb + l]), s, c);
-                else { const int t = e - a.m_rx; sincos_rev(frac_rev((double)(t % a.bs_mh) * ws.tx_y[rb + l] + (double)(t / a.bs_mh) * ws.tx_z[rb + l]), s, c); }
-            }
-            tab[i] = make_float2(c, s);
-        }
-        __syncthreads();
-        const int r = tid & 255, l0 = (tid >> 8) * LPER;
-        const int p = row0 + r;
-        const bool rok = r < a.rows, pok = rok && p < a.M;
-        const int rx = pok ? p / a.m_tx : 0, tx = pok ? p - rx * a.m_tx : 0;
-        h2 lo_keep[LPER];
-        if (rok) {
-            h2* rhi = reinterpret_cast<h2*>(Ahi + (size_t)r * ROW_BYTES);
-            const float2* trx = tab + (size_t)rx * LPAD;
-            const float2* ttx = tab + (size_t)(a.m_rx + tx) * LPAD;
-#pragma unroll
-            for (int j = 0; j < LPER; ++j) {
-                const int l = l0 + j;
-                h2 vh = {(_Float16)0.f, (_Float16)0.f};
-                lo_keep[j] = vh;
-                if (pok && l < n_act) {
-                    const float2 u1 = trx[l], u2 = ttx[l];
-                    split2_f16((u1.x * u2.x - u1.y * u2.y) * A_SCALE, (u1.x * u2.y + u1.y * u2.x) * A_SCALE, vh, lo_keep[j]);
-                }
-                rhi[l] = vh;
-            }
-        }
-        __syncthreads();                                            // every table read is done: the region becomes Alo
-        if (rok) {
-            h2* rlo = reinterpret_cast<h2*>(Alo + (size_t)r * ROW_BYTES);
-#pragma unroll
-            for (int j = 0; j < LPER; ++j) rlo[l0 + j] = lo_keep[j];
         }
     }
     __syncthreads();
@@ -614,9 +569,6 @@ static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user
     a.nblk = (a.M + MAX_ROWS - 1) / MAX_ROWS;
     const int mrows = a.M < MAX_ROWS ? a.M : MAX_ROWS;
     a.rows = (mrows + 31) / 32 * 32;
-    // factor tables need (M_rx + M_tx) * 32 * 8 B inside the lo-tile region and pay off when they replace more
-    // sin/cos than they cost
-    a.factored = !n_beams && (size_t)(a.m_rx + a.m_tx) * LPAD * 8 <= (size_t)a.rows * ROW_BYTES && (a.m_rx + a.m_tx) * 2 <= a.M;
     const size_t smem = (size_t)2 * a.rows * ROW_BYTES + LPAD * (8 + 4 + 4) + 16;
     const int64_t blocks = user_count * a.nblk;
     if (blocks > 0x7fffffffLL) { set_error("too many workgroups for one call"); return DMX_ERR_SHAPE; }
