@@ -276,16 +276,21 @@ int launch_channels_fd_mfma(const dmx_params& prm, const WsView& ws, int64_t use
                             float2* out, int config, hipStream_t stream);
 bool fd_mfma_supported(const dmx_params& prm, const WsView& ws);
 bool fd_mfma_preferred(const dmx_params& prm, const WsView& ws);
+int launch_channels_fd_small(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
+                             float2* out, hipStream_t stream);
+bool fd_small_preferred(const dmx_params& prm, const WsView& ws);
 
 int launch_channels_fd(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
                        float2* out, int variant, hipStream_t stream) {
     if (user_count == 0) return DMX_OK;
-    if (variant >= 2 && !fd_mfma_supported(prm, ws)) {
+    if (variant >= 2 && variant != 9 && !fd_mfma_supported(prm, ws)) {
         set_error("MFMA variant does not support this shape");
         return DMX_ERR_SHAPE;
     }
     int rc;
-    if (variant >= 2 || (variant == 0 && fd_mfma_preferred(prm, ws)))
+    if (variant == 9 || (variant == 0 && fd_small_preferred(prm, ws)))
+        rc = launch_channels_fd_small(prm, ws, user_begin, user_count, out, stream);
+    else if (variant >= 2 || (variant == 0 && fd_mfma_preferred(prm, ws)))
         rc = launch_channels_fd_mfma(prm, ws, user_begin, user_count, out, variant >= 3 ? variant - 2 : 0, stream);
     else
         rc = launch_fd_valu_any(prm, ws, user_begin, user_count, nullptr, out, stream);

@@ -473,10 +473,12 @@ bool fd_mfma_supported(const dmx_params& prm, const WsView& ws) {
     return prm.n_selected >= 1;
 }
 
-// automatic choice: the matrix-core kernel pays off once a 32-row tile is mostly full
+// automatic choice: the matrix-core kernel pays off once a 32-row tile is mostly full.  (Few subcarriers go to the
+// small-output kernel first, k2_channel_fd_small.hip; what is left of them here still beats the subcarrier-per-lane
+// kernel, which idles 64 - K lanes: 16 vs 79 ms at 1024 pairs x 2 subcarriers.)
 bool fd_mfma_preferred(const dmx_params& prm, const WsView& ws) {
     const int M = prm.ue_shape[0] * prm.ue_shape[1] * prm.bs_shape[0] * prm.bs_shape[1];
-    return fd_mfma_supported(prm, ws) && M >= 24 && prm.n_selected >= 8;
+    return fd_mfma_supported(prm, ws) && M >= 24;
 }
 
 template <bool NT, int NW, int SPW>

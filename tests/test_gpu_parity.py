@@ -137,13 +137,31 @@ SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [1, 0, 4, 5])
-@pytest.mark.parametrize("shape", SHAPES, ids=[f"s{i}" for i in range(len(SHAPES))])
+SHAPES_SMALL = [
+    # few selected subcarriers - the small-output kernel's regime (the reference default is ONE subcarrier)
+    (70, 25, [8, 8], [1, 1], 512, [0], {}),
+    (70, 25, [8, 8], [2, 2], 512, [0, 1], dict(bs_rot=[10, 0, -30])),
+    (41, 10, [8, 1], [1, 1], 64, [3, 9, 27], dict(ue_rot=[0, 20, 40])),                 # K = 3: chunk tail at KC = 2
+    (33, 25, [4, 4], [2, 1], 512, list(range(0, 512, 103)), {}),                        # K = 5: chunk tail at KC = 4
+    (29, 32, [8, 4], [1, 2], 256, list(range(8)), dict(all_valid=True, max_delay=20e-6)),
+    (260, 7, [2, 2], [1, 1], 64, list(range(64)), {}),                                  # more users than one grid pass of waves
+]
+
+
+def _small_kernel_fits(shape):
+    n, L, bs, ue, N, sel, extra = shape
+    return (bs[0] * bs[1] + ue[0] * ue[1] + len(sel)) * min(L, 32) * 8 <= 156 * 1024
+
+
+@pytest.mark.parametrize("variant", [1, 0, 4, 5, 9])
+@pytest.mark.parametrize("shape", SHAPES + SHAPES_SMALL, ids=[f"s{i}" for i in range(len(SHAPES) + len(SHAPES_SMALL))])
 def test_vs_oracle_shapes(shape, variant):
     """Seeded synthetic rays at ragged shapes (K not a multiple of 64, odd panels, 1..32 paths)."""
     import deepmimo_amd as dm
     from oracle import oracle_np as onp
     n, L, bs, ue, N, sel, extra = shape
+    if variant == 9 and not _small_kernel_fits(shape):
+        pytest.skip("one user's factor tables exceed the LDS of the small-output kernel")
     rays = onp.synth_rays(n, L, seed=1000 + n, all_valid=extra.get("all_valid", False),
                           max_delay=extra.get("max_delay", 2e-6))
     case = dict(bs_shape=bs, ue_shape=ue, bs_spacing=0.5, ue_spacing=0.37, bs_rot=extra.get("bs_rot", [0, 0, 0]),
