@@ -38,6 +38,7 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 
 static constexpr int ROW_BYTES = 144;        // 64 f16 + 16 B pad
 static constexpr int MAX_ROWS = 256;         // antenna pairs per workgroup
+static constexpr int MFMA_LDS_MAX = 80 * 1024;   // two workgroups per CU
 static constexpr int LPAD = 32;              // path slots (kk = 64)
 static constexpr float A_SCALE = 64.0f;      // 2^6
 
@@ -70,88 +71,149 @@ __device__ __forceinline__ void split2_f16(float x0, float x1, h2& hi, h2& lo) {
 
 // B' fragments of one lane for strip `strip` (32 columns = 16 subcarriers, re/im interleaved): element j of
 // K-step s is row kk = 16s + 8h + j of B', i.e. path l = 8s + 4h + (j>>1), component j&1.
-__device__ __forceinline__ void gen_b_fragments(int strip, int col, int hh, size_t twoK, const int32_t* __restrict__ sc,
-                                                int n_act, const double* qtab, const float* crtab, const float* citab,
-                                                const float2* __restrict__ grow, int K, float gs,
-                                                h8 (&Bhi)[4], h8 (&Blo)[4], bool& kok, unsigned& lane_off) {
+struct BLane {                      // what a lane knows about its column of the strip
+    int kidx, c;                    // subcarrier index in the selection, re/im column
+    bool kok;                       // column inside the selection
+    unsigned lane_off;              // byte offset of (row 4h, this column) inside a 32-row tile of the output
+    double kk;                      // selected subcarrier number
+};
+
+__device__ __forceinline__ BLane b_lane(int strip, int col, int hh, size_t twoK, const int32_t* __restrict__ sc) {
+    BLane b;
     const int ncol = (strip << 5) + col;                                // column of C = 2*kidx + c
-    const int kidx = ncol >> 1, c = ncol & 1;
-    kok = (size_t)ncol < twoK;
-    lane_off = ((unsigned)(4 * hh) * (unsigned)twoK + (unsigned)ncol) * 4u;
-    const double kk = (double)(kok ? sc[kidx] : 0);
+    b.kidx = ncol >> 1; b.c = ncol & 1;
+    b.kok = (size_t)ncol < twoK;
+    b.lane_off = ((unsigned)(4 * hh) * (unsigned)twoK + (unsigned)ncol) * 4u;
+    b.kk = (double)(b.kok ? sc[b.kidx] : 0);
+    return b;
+}
+
+// one K-step (8 paths) of the strip's B' fragments
+__device__ __forceinline__ void gen_b_step(int s, const BLane& bl, int hh, int n_act, const double* qtab, const float* crtab,
+                                           const float* citab, const float2* __restrict__ grow, int K, float gs,
+                                           h8& Bhi, h8& Blo) {
+    Bhi = h8{0, 0, 0, 0, 0, 0, 0, 0};
+    Blo = Bhi;
+    if (8 * s >= n_act) return;
+    const int c = bl.c;
+    // this lane evaluates paths jj = 2c, 2c+1 of the step, its pair lane (same subcarrier, other re/im column)
+    // the other two; swap through a lane-pair shuffle
+    float mr[2], mi[2], orr[2], oi[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int pl = 8 * s + 4 * hh + 2 * c + t;
+        if (grow) {                                                     // rx_filter: G[l,k] from the k3 table
+            float2 g = make_float2(0.f, 0.f);
+            if (bl.kok && pl < n_act) g = grow[(size_t)pl * K + bl.kidx];
+            mr[t] = g.x * gs; mi[t] = g.y * gs;
+        } else {
+            float sn, cs;
+            sincos_rev(frac_rev(qtab[pl] * bl.kk), sn, cs);
+            const float cr = crtab[pl], ci = citab[pl];
+            mr[t] = cr * cs + ci * sn;                                  // Re c*exp(-j x)
+            mi[t] = ci * cs - cr * sn;                                  // Im
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { orr[t] = __shfl_xor(mr[t], 1); oi[t] = __shfl_xor(mi[t], 1); }
+    float gr[4], gi[4];
+    gr[0] = c ? orr[0] : mr[0]; gi[0] = c ? oi[0] : mi[0];
+    gr[1] = c ? orr[1] : mr[1]; gi[1] = c ? oi[1] : mi[1];
+    gr[2] = c ? mr[0] : orr[0]; gi[2] = c ? mi[0] : oi[0];
+    gr[3] = c ? mr[1] : orr[1]; gi[3] = c ? mi[1] : oi[1];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const float e0 = c ? gi[jj] : gr[jj];                           // row 2l   : Re G (re col) / Im G (im col)
+        const float e1 = c ? gr[jj] : -gi[jj];                          // row 2l+1 : -Im G        / Re G
+        h2 ph, pl2;
+        split2_f16(e0, e1, ph, pl2);
+        Bhi[2 * jj] = ph[0]; Bhi[2 * jj + 1] = ph[1];
+        Blo[2 * jj] = pl2[0]; Blo[2 * jj + 1] = pl2[1];
+    }
+}
+
+// One 32-row tile of one strip: 8 ds_read_b128 of A', 12 MFMAs, 16 stores.
+// 32x32 accumulator: column on the lane, register i is row (i&3) + 8*(i>>2) + 4*(lane>>5).  Output through a
+// buffer descriptor over this workgroup's row block: the per-lane part of the address is one 32-bit voffset per
+// strip, the row of each store is a scalar soffset, and rows past the block end fall outside num_records and are
+// dropped by the hardware range check.
+template <bool NT>
+__device__ __forceinline__ void mfma_tile(int pt, const unsigned char* Ahi, const unsigned char* Alo, int col, int hh, int n_act,
+                                          const h8 (&Bhi)[4], const h8 (&Blo)[4], const BLane& bl,
+                                          __amdgpu_buffer_rsrc_t orsrc, unsigned row_bytes, float oscale) {
+    f16v acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const size_t abase = (size_t)((pt << 5) + col) * ROW_BYTES + (size_t)hh * 16;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        Bhi[s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
-        Blo[s] = Bhi[s];
         if (8 * s < n_act) {
-            // this lane evaluates paths jj = 2c, 2c+1 of the step, its pair lane (same subcarrier,
-            // other re/im column) the other two; swap through a lane-pair shuffle
-            float mr[2], mi[2], orr[2], oi[2];
+            const h8 ah = *reinterpret_cast<const h8*>(Ahi + abase + s * 32);
+            const h8 al = *reinterpret_cast<const h8*>(Alo + abase + s * 32);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bhi[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Blo[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bhi[s], acc, 0, 0, 0);
+        }
+    }
+    if (bl.kok) {
+        const unsigned tile_off = (unsigned)(pt << 5) * row_bytes;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int pl = 8 * s + 4 * hh + 2 * c + t;
-                if (grow) {                                             // rx_filter: G[l,k] from the k3 table
-                    float2 g = make_float2(0.f, 0.f);
-                    if (kok && pl < n_act) g = grow[(size_t)pl * K + kidx];
-                    mr[t] = g.x * gs; mi[t] = g.y * gs;
-                } else {
-                    float sn, cs;
-                    sincos_rev(frac_rev(qtab[pl] * kk), sn, cs);
-                    const float cr = crtab[pl], ci = citab[pl];
-                    mr[t] = cr * cs + ci * sn;                          // Re c*exp(-j x)
-                    mi[t] = ci * cs - cr * sn;                          // Im
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) { orr[t] = __shfl_xor(mr[t], 1); oi[t] = __shfl_xor(mi[t], 1); }
-            float gr[4], gi[4];
-            gr[0] = c ? orr[0] : mr[0]; gi[0] = c ? oi[0] : mi[0];
-            gr[1] = c ? orr[1] : mr[1]; gi[1] = c ? oi[1] : mi[1];
-            gr[2] = c ? mr[0] : orr[0]; gi[2] = c ? mi[0] : oi[0];
-            gr[3] = c ? mr[1] : orr[1]; gi[3] = c ? mi[1] : oi[1];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const float e0 = c ? gi[jj] : gr[jj];                   // row 2l   : Re G (re col) / Im G (im col)
-                const float e1 = c ? gr[jj] : -gi[jj];                  // row 2l+1 : -Im G        / Re G
-                h2 ph, pl2;
-                split2_f16(e0, e1, ph, pl2);
-                Bhi[s][2 * jj] = ph[0]; Bhi[s][2 * jj + 1] = ph[1];
-                Blo[s][2 * jj] = pl2[0]; Blo[s][2 * jj + 1] = pl2[1];
-            }
+        for (int i = 0; i < 16; ++i) {
+            const unsigned soff = tile_off + (unsigned)((i & 3) + 8 * (i >> 2)) * row_bytes;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[i] * oscale), orsrc, bl.lane_off, soff, NT ? 2 : 0);
         }
     }
 }
 
-// NW = waves per workgroup (4, 8 or 16): the A' tiles in LDS are shared by all of them, so more waves per
-// workgroup mean more waves in flight per CU (LDS, not registers, limits occupancy here: 74 KB per
-// workgroup -> 2 workgroups per CU).  Measured at the headline config: 19.4 / 19.0 / 18.4 ms for 4 / 8 / 16.
-template <bool NT, int NW, int SPW>
-__device__ __forceinline__ void mfma_block(const WsView& ws, const MfmaArgs& a, float* __restrict__ out, int64_t work,
-                                           unsigned char* smem) {
-    constexpr int NTHR = NW * 64;
-    unsigned char* Ahi = smem;                                          // [rows][144 B]
-    unsigned char* Alo = smem + (size_t)a.rows * ROW_BYTES;
-    double* qtab = reinterpret_cast<double*>(smem + (size_t)2 * a.rows * ROW_BYTES);   // [32] dn_l / N
-    float* crtab = reinterpret_cast<float*>(qtab + LPAD);                             // [32] scaled c_l
-    float* citab = crtab + LPAD;
-    float* misc = citab + LPAD;                                         // [4] per-user output scale
+// What one (user, row block) work item keeps in LDS: the A' hi / lo tiles and the per-user path tables.
+struct ItemLds {
+    unsigned char* Ahi;      // [rows][144 B]
+    unsigned char* Alo;
+    double* qtab;            // [32] dn_l / N
+    float* crtab;            // [32] scaled c_l
+    float* citab;
+    float* misc;             // [4]  per-user output / operand scales
+};
+__host__ __device__ inline size_t item_lds_bytes(int rows) { return (size_t)2 * rows * ROW_BYTES + LPAD * (8 + 4 + 4) + 16; }
+__device__ __forceinline__ ItemLds item_lds(unsigned char* base, int rows) {
+    ItemLds L;
+    L.Ahi = base;
+    L.Alo = base + (size_t)rows * ROW_BYTES;
+    L.qtab = reinterpret_cast<double*>(base + (size_t)2 * rows * ROW_BYTES);
+    L.crtab = reinterpret_cast<float*>(L.qtab + LPAD);
+    L.citab = L.crtab + LPAD;
+    L.misc = L.citab + LPAD;
+    return L;
+}
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t ul = work / a.nblk;
+struct ItemPos {
+    int64_t ul, u;
+    int row0, nrows, n_act;
+    size_t rb;
+};
+__device__ __forceinline__ ItemPos item_pos(const WsView& ws, const MfmaArgs& a, int64_t work) {
+    ItemPos p;
+    p.ul = work / a.nblk;
     const int blk = (int)(work % a.nblk);
-    const int64_t u = a.user_begin + ul;
-    const int row0 = blk * MAX_ROWS;
-    const int nrows = (a.M - row0) < MAX_ROWS ? (a.M - row0) : MAX_ROWS;   // valid rows of this block
-    const size_t twoK = (size_t)2 * a.K;
-    float* __restrict__ o = out + ((size_t)ul * a.M + row0) * twoK;
-    int n_act = ws.n_keep[u];
-    n_act = n_act < LPAD ? n_act : LPAD;
-    if (n_act == 0) {                                                    // channel.py:270-271
-        const size_t nel = (size_t)nrows * twoK;
-        for (size_t i = tid; i < nel; i += NTHR) o[i] = 0.f;
-        return;
-    }
-    const size_t rb = (size_t)u * ws.P;
+    p.u = a.user_begin + p.ul;
+    p.row0 = blk * MAX_ROWS;
+    p.nrows = (a.M - p.row0) < MAX_ROWS ? (a.M - p.row0) : MAX_ROWS;     // valid rows of this block
+    const int n = ws.n_keep[p.u];
+    p.n_act = n < LPAD ? n : LPAD;
+    p.rb = (size_t)p.u * ws.P;
+    return p;
+}
+
+// Stage 1 of a work item: the per-user tables (wave 0) and the A' tiles (thread = antenna pair x slice of the path
+// slots) into `L`.  No barrier inside; nothing here reads what another thread of this call wrote.
+// NW = waves per workgroup (4, 8 or 16).
+template <int NW>
+__device__ __forceinline__ void stage_item(const WsView& ws, const MfmaArgs& a, int64_t work, const ItemLds& L) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const ItemPos ip = item_pos(ws, a, work);
+    const int n_act = ip.n_act;
+    if (n_act == 0) return;                                              // consume_item writes zeros, reads nothing
+    const size_t rb = ip.rb;
 
     // per-user power-of-two scale: max |c_l| component -> [512, 1024)
     if (wave == 0) {
@@ -163,131 +225,106 @@ __device__ __forceinline__ void mfma_block(const WsView& ws, const MfmaArgs& a, 
         const float gs = ldexpf(1.0f, 10 - e);
         if (lane < LPAD) {
             const bool ok = lane < n_act;
-            qtab[lane] = ok ? (double)ws.dn[rb + lane] * a.inv_n : 0.0;
-            crtab[lane] = ok ? ws.c_re[rb + lane] * gs : 0.f;
-            citab[lane] = ok ? ws.c_im[rb + lane] * gs : 0.f;
+            L.qtab[lane] = ok ? (double)ws.dn[rb + lane] * a.inv_n : 0.0;
+            L.crtab[lane] = ok ? ws.c_re[rb + lane] * gs : 0.f;
+            L.citab[lane] = ok ? ws.c_im[rb + lane] * gs : 0.f;
         }
         // A' scale: 64 for unit-modulus array responses; with a codebook the projected responses f are
         // scaled per user so that max |f| lands in [32, 64)
-        const int ea = a.n_beams ? 6 - a.fexp[ul] : 6;
+        const int ea = a.n_beams ? 6 - a.fexp[ip.ul] : 6;
         // rx_filter: |G| can exceed |c| by the sinc sum (a few x); two bits of headroom keep G*gs < 2^13
         if (a.gtab) e += 2;
-        if (lane == 0) { misc[0] = ldexpf(1.0f, e - 10 - ea); misc[1] = ldexpf(1.0f, ea); misc[2] = ldexpf(1.0f, 10 - e); }
+        if (lane == 0) { L.misc[0] = ldexpf(1.0f, e - 10 - ea); L.misc[1] = ldexpf(1.0f, ea); L.misc[2] = ldexpf(1.0f, 10 - e); }
     }
 
-    // phase 1: A' tiles.  thread = (row = antenna pair, slice of the path slots)
     constexpr int LSPLIT = NW / 4, LPER = LPAD / LSPLIT;
-    {
-        const int r = tid & 255, l0 = (tid >> 8) * LPER;
-        if (r < a.rows) {
-            const int p = row0 + r;
-            const bool pok = p < a.M;
-            const int ncolA = a.n_beams ? a.n_beams : a.m_tx;              // second index of the row pair
-            const int rx = pok ? p / ncolA : 0, tx = pok ? p - rx * ncolA : 0;
-            const double yr = (double)(rx % a.ue_mh), zr = (double)(rx / a.ue_mh);
-            const double yt = (double)(tx % a.bs_mh), zt = (double)(tx / a.bs_mh);
-            h2* rhi = reinterpret_cast<h2*>(Ahi + (size_t)r * ROW_BYTES);
-            h2* rlo = reinterpret_cast<h2*>(Alo + (size_t)r * ROW_BYTES);
-            if (a.n_beams) {
-                // beam-space rows: A[(rx,b), l] = a_rx[rx,l] * f[b,l]  (f from k2b_beam_project)
-                const float2* frow = a.ftab + ((size_t)ul * a.n_beams + tx) * ws.P;
-                const float ascale = ldexpf(1.0f, 6 - a.fexp[ul]);
-                for (int l = l0; l < l0 + LPER; ++l) {
-                    h2 vh = {(_Float16)0.f, (_Float16)0.f}, vl = vh;
-                    if (pok && l < n_act) {
-                        float s, c;
-                        sincos_rev(frac_rev(yr * ws.rx_y[rb + l] + zr * ws.rx_z[rb + l]), s, c);
-                        const float2 f = frow[l];
-                        split2_f16((c * f.x - s * f.y) * ascale, (c * f.y + s * f.x) * ascale, vh, vl);
-                    }
-                    rhi[l] = vh;
-                    rlo[l] = vl;
-                }
-            } else {
-                for (int l = l0; l < l0 + LPER; ++l) {
-                    h2 vh = {(_Float16)0.f, (_Float16)0.f}, vl = vh;
-                    if (pok && l < n_act) {
-                        const double ph = yr * ws.rx_y[rb + l] + zr * ws.rx_z[rb + l] + yt * ws.tx_y[rb + l] + zt * ws.tx_z[rb + l];
-                        float s, c;
-                        sincos_rev(frac_rev(ph), s, c);
-                        split2_f16(c * A_SCALE, s * A_SCALE, vh, vl);
-                    }
-                    rhi[l] = vh;
-                    rlo[l] = vl;
-                }
+    const int r = tid & 255, l0 = (tid >> 8) * LPER;
+    if (r >= a.rows) return;
+    const int p = ip.row0 + r;
+    const bool pok = p < a.M;
+    const int ncolA = a.n_beams ? a.n_beams : a.m_tx;                    // second index of the row pair
+    const int rx = pok ? p / ncolA : 0, tx = pok ? p - rx * ncolA : 0;
+    const double yr = (double)(rx % a.ue_mh), zr = (double)(rx / a.ue_mh);
+    const double yt = (double)(tx % a.bs_mh), zt = (double)(tx / a.bs_mh);
+    h2* rhi = reinterpret_cast<h2*>(L.Ahi + (size_t)r * ROW_BYTES);
+    h2* rlo = reinterpret_cast<h2*>(L.Alo + (size_t)r * ROW_BYTES);
+    if (a.n_beams) {
+        // beam-space rows: A[(rx,b), l] = a_rx[rx,l] * f[b,l]  (f from k2b_beam_project)
+        const float2* frow = a.ftab + ((size_t)ip.ul * a.n_beams + tx) * ws.P;
+        const float ascale = ldexpf(1.0f, 6 - a.fexp[ip.ul]);
+        for (int l = l0; l < l0 + LPER; ++l) {
+            h2 vh = {(_Float16)0.f, (_Float16)0.f}, vl = vh;
+            if (pok && l < n_act) {
+                float s, c;
+                sincos_rev(frac_rev(yr * ws.rx_y[rb + l] + zr * ws.rx_z[rb + l]), s, c);
+                const float2 f = frow[l];
+                split2_f16((c * f.x - s * f.y) * ascale, (c * f.y + s * f.x) * ascale, vh, vl);
             }
+            rhi[l] = vh;
+            rlo[l] = vl;
         }
-    }
-    __syncthreads();
-    const float oscale = misc[0];
-    const float gscale = misc[2];
-    const float2* grow = a.gtab ? a.gtab + (size_t)ul * ws.P * a.K : nullptr;
-
-    const int col = lane & 31, hh = lane >> 5;
-    const unsigned row_bytes = (unsigned)twoK * 4u;
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(o, 0, (int)((unsigned)nrows * row_bytes), 0x00020000);
-    const int nstrips = (int)((twoK + 31) >> 5);
-    const int ngroups = (nstrips + SPW - 1) / SPW;
-    const int ntiles = (nrows + 31) >> 5;
-    // A wave owns SPW adjacent 32-column strips at a time and walks the row tiles with all of them, so the
-    // 16 (8) waves of the workgroup fill one 32-row band of the user's block together: A' fragments are
-    // read from LDS once per tile for SPW strips and the stores of a workgroup stay within a few DRAM pages.
-    for (int grp = wave; grp < ngroups; grp += NW) {
-        h8 Bhi[SPW][4], Blo[SPW][4];
-        unsigned lane_off[SPW];
-        bool kok[SPW];
-#pragma unroll
-        for (int j = 0; j < SPW; ++j)
-            gen_b_fragments(grp * SPW + j, col, hh, twoK, a.sc, n_act, qtab, crtab, citab, grow, a.K, gscale, Bhi[j], Blo[j], kok[j], lane_off[j]);
-
-        for (int pt = 0; pt < ntiles; ++pt) {
-            f16v acc[SPW];
-#pragma unroll
-            for (int j = 0; j < SPW; ++j)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-            const size_t abase = (size_t)((pt << 5) + col) * ROW_BYTES + (size_t)hh * 16;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if (8 * s < n_act) {
-                    const h8 ah = *reinterpret_cast<const h8*>(Ahi + abase + s * 32);
-                    const h8 al = *reinterpret_cast<const h8*>(Alo + abase + s * 32);
-#pragma unroll
-                    for (int j = 0; j < SPW; ++j) {
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bhi[j][s], acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Blo[j][s], acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bhi[j][s], acc[j], 0, 0, 0);
-                    }
-                }
+    } else {
+        for (int l = l0; l < l0 + LPER; ++l) {
+            h2 vh = {(_Float16)0.f, (_Float16)0.f}, vl = vh;
+            if (pok && l < n_act) {
+                const double ph = yr * ws.rx_y[rb + l] + zr * ws.rx_z[rb + l] + yt * ws.tx_y[rb + l] + zt * ws.tx_z[rb + l];
+                float s, c;
+                sincos_rev(frac_rev(ph), s, c);
+                split2_f16(c * A_SCALE, s * A_SCALE, vh, vl);
             }
-            // 32x32 accumulator: column on the lane, register i is row (i&3) + 8*(i>>2) + 4*(lane>>5).
-            // Output through a buffer descriptor over this workgroup's row block: the per-lane part of the
-            // address is one 32-bit voffset per strip, the row of each store is a scalar soffset, and rows
-            // past the block end fall outside num_records and are dropped by the hardware range check.
-            const unsigned tile_off = (unsigned)(pt << 5) * row_bytes;
-#pragma unroll
-            for (int j = 0; j < SPW; ++j) {
-                if (kok[j]) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const unsigned soff = tile_off + (unsigned)((i & 3) + 8 * (i >> 2)) * row_bytes;
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[j][i] * oscale), orsrc, lane_off[j], soff, NT ? 2 : 0);
-                    }
-                }
-            }
+            rhi[l] = vh;
+            rlo[l] = vl;
         }
     }
 }
 
+// Stage 2 of a work item, after a barrier behind stage_item: a wave owns one 32-column strip at a time (B'
+// fragments in registers) and walks the row tiles with it, so the waves of the workgroup fill one 32-row band of the
+// user's block together and their stores stay within a few DRAM pages.  No barrier inside.
+template <bool NT, int NW>
+__device__ __forceinline__ void consume_item(const WsView& ws, const MfmaArgs& a, float* __restrict__ out, int64_t work,
+                                             const ItemLds& L) {
+    constexpr int NTHR = NW * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const ItemPos ip = item_pos(ws, a, work);
+    const size_t twoK = (size_t)2 * a.K;
+    float* __restrict__ o = out + ((size_t)ip.ul * a.M + ip.row0) * twoK;
+    const int n_act = ip.n_act;
+    if (n_act == 0) {                                                    // channel.py:270-271
+        const size_t nel = (size_t)ip.nrows * twoK;
+        for (size_t i = tid; i < nel; i += NTHR) o[i] = 0.f;
+        return;
+    }
+    const float oscale = L.misc[0];
+    const float gscale = L.misc[2];
+    const float2* grow = a.gtab ? a.gtab + (size_t)ip.ul * ws.P * a.K : nullptr;
+
+    const int col = lane & 31, hh = lane >> 5;
+    const unsigned row_bytes = (unsigned)twoK * 4u;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(o, 0, (int)((unsigned)ip.nrows * row_bytes), 0x00020000);
+    const int nstrips = (int)((twoK + 31) >> 5);
+    const int ntiles = (ip.nrows + 31) >> 5;
+    for (int strip = wave; strip < nstrips; strip += NW) {
+        const BLane bl = b_lane(strip, col, hh, twoK, a.sc);
+        h8 Bhi[4], Blo[4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) gen_b_step(st, bl, hh, n_act, L.qtab, L.crtab, L.citab, grow, a.K, gscale, Bhi[st], Blo[st]);
+        for (int pt = 0; pt < ntiles; ++pt)
+            mfma_tile<NT>(pt, L.Ahi, L.Alo, col, hh, n_act, Bhi, Blo, bl, orsrc, row_bytes, oscale);
+    }
+}
+
 // One (user, row block) per loop iteration.  Launched with one workgroup per work item, or persistently (grid =
-// what is resident at once, workgroups stride over the work items): every phase is workgroup-uniform, so the only
-// extra synchronisation is the barrier that keeps the next item's A' tiles from overwriting the current ones.
-template <bool NT, int NW, int SPW>
+// what is resident at once, workgroups stride over the work items).
+template <bool NT, int NW>
 __global__ __launch_bounds__(NW * 64) void k2_fd_mfma(WsView ws, MfmaArgs a, float* __restrict__ out, int64_t total) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const ItemLds L = item_lds(smem, a.rows);
     for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
-        mfma_block<NT, NW, SPW>(ws, a, out, w, smem);
+        stage_item<NW>(ws, a, w, L);
         __syncthreads();
+        consume_item<NT, NW>(ws, a, out, w, L);
+        __syncthreads();                                                 // the next item's tiles overwrite these
     }
 }
 
@@ -481,23 +518,29 @@ bool fd_mfma_preferred(const dmx_params& prm, const WsView& ws) {
     return fd_mfma_supported(prm, ws) && M >= 24;
 }
 
-template <bool NT, int NW, int SPW>
+// persistent launches: as many workgroups as the device keeps resident at once (registers and LDS decide: ask the
+// runtime), each striding over the work items
+static int64_t resident_grid(const void* kfn, int threads, size_t smem, int64_t blocks) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, threads, smem) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 1;
+    }
+    const int64_t resident = (int64_t)256 * per_cu;
+    return blocks < resident ? blocks : resident;
+}
+
+template <bool NT, int NW>
 static int launch_mfma_t(const WsView& ws, const MfmaArgs& a, int64_t blocks, size_t smem, float2* out, hipStream_t stream,
                          bool persistent = true) {
-    const void* kfn = reinterpret_cast<const void*>(k2_fd_mfma<NT, NW, SPW>);
+    const void* kfn = reinterpret_cast<const void*>(k2_fd_mfma<NT, NW>);
     if (smem > 64 * 1024) {     // per device and cheap: no cached flag, so every GPU of a process gets it
-        hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MAX_ROWS * ROW_BYTES + 1024);
+        hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, MFMA_LDS_MAX);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
     }
     int64_t grid = blocks;
-    if (persistent) {                                           // workgroups resident at once on 256 CUs (32 waves per CU)
-        int per_cu = 32 / NW;
-        const int by_lds = (int)((size_t)160 * 1024 / (smem ? smem : 1));
-        if (by_lds < per_cu) per_cu = by_lds > 0 ? by_lds : 1;
-        const int64_t resident = (int64_t)256 * per_cu;
-        if (grid > resident) grid = resident;
-    }
-    hipLaunchKernelGGL((k2_fd_mfma<NT, NW, SPW>), dim3((unsigned)grid), dim3(NW * 64), smem, stream, ws, a, reinterpret_cast<float*>(out), blocks);
+    if (persistent) grid = resident_grid(kfn, NW * 64, smem, blocks);
+    hipLaunchKernelGGL((k2_fd_mfma<NT, NW>), dim3((unsigned)grid), dim3(NW * 64), smem, stream, ws, a, reinterpret_cast<float*>(out), blocks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("k2_fd_mfma launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
     return DMX_OK;
@@ -568,10 +611,11 @@ static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user
     a.K = prm.n_selected;
     a.sc = prm.selected_subcarriers;
     a.inv_n = 1.0 / (double)prm.n_subcarriers;
+    const int nstrips = (2 * a.K + 31) / 32;
     a.nblk = (a.M + MAX_ROWS - 1) / MAX_ROWS;
     const int mrows = a.M < MAX_ROWS ? a.M : MAX_ROWS;
     a.rows = (mrows + 31) / 32 * 32;
-    const size_t smem = (size_t)2 * a.rows * ROW_BYTES + LPAD * (8 + 4 + 4) + 16;
+    const size_t smem = item_lds_bytes(a.rows);
     const int64_t blocks = user_count * a.nblk;
     if (blocks > 0x7fffffffLL) { set_error("too many workgroups for one call"); return DMX_ERR_SHAPE; }
     if ((size_t)a.rows * (size_t)a.K * 8 >= (size_t)1 << 31) {      // buffer descriptor / 32-bit offsets per row block
@@ -579,13 +623,20 @@ static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user
         return DMX_ERR_SHAPE;
     }
     switch (config) {
-        case 1: return launch_mfma_t<false, 16, 1>(ws, a, blocks, smem, out, stream);   // plain stores
-        case 2: return launch_mfma_t<true, 4, 1>(ws, a, blocks, smem, out, stream);
-        case 3: return launch_mfma_t<true, 8, 1>(ws, a, blocks, smem, out, stream);
-        case 4: return launch_mfma_t<true, 8, 2>(ws, a, blocks, smem, out, stream);
-        case 5: return launch_mfma_t<true, 16, 2>(ws, a, blocks, smem, out, stream);
-        case 6: return launch_mfma_t<true, 16, 1>(ws, a, blocks, smem, out, stream, false);     // one workgroup per work item
-        default: return launch_mfma_t<true, 16, 1>(ws, a, blocks, smem, out, stream);
+        case 1: return launch_mfma_t<false, 16>(ws, a, blocks, smem, out, stream);   // plain stores
+        case 2: return launch_mfma_t<true, 4>(ws, a, blocks, smem, out, stream);
+        case 3: return launch_mfma_t<true, 8>(ws, a, blocks, smem, out, stream);
+        case 6: return launch_mfma_t<true, 16>(ws, a, blocks, smem, out, stream, false);     // one workgroup per work item
+        case 8: return launch_mfma_t<true, 16>(ws, a, blocks, smem, out, stream);            // 16 waves whatever the strip count
+        case 0:
+            // Registers (~125 VGPRs) hold this kernel to 4 waves per SIMD, i.e. ONE 16-wave workgroup per CU, whose
+            // phases nothing overlaps.  With up to 8 strips (K <= 128) a wave per strip leaves waves idle anyway, and
+            // 4-wave workgroups, two or three per CU overlapping each other, are 5-40 % faster (tools/ab_bench.py,
+            // variants 10 vs 4: 3.29 -> 2.34 ms at 256 pairs x 16 subcarriers, 5.65 -> 5.34 at x 128; at x 512 the
+            // 16-wave form wins 18.1 vs 19.2: there the stream of stores is the bound and more waves feed it).
+            if (nstrips <= 8) return launch_mfma_t<true, 4>(ws, a, blocks, smem, out, stream);
+            return launch_mfma_t<true, 16>(ws, a, blocks, smem, out, stream);
+        default: set_error("unknown matrix-core kernel configuration %d", config); return DMX_ERR_ARG;
     }
 }
 

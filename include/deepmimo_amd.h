@@ -126,10 +126,10 @@ int dmx_path_prep(const dmx_rays* rays, const dmx_params* prm, void* workspace, 
  * for users [user_begin, user_begin + user_count) of the prepared workspace; `out` points at the
  * first of those users (complex64 [user_count, M_rx, M_tx, K]).
  * variant: 0 = automatic; 1 = fp32 vector kernel; 2 = split-precision MFMA kernel (persistent 16-wave
- *          workgroups, non-temporal output stores).  Tuning knobs kept for A/B measurements: 3 = MFMA with
- *          plain stores, 4 / 5 = 4- / 8-wave workgroups, 6 / 7 = two strips per wave with 8 / 16 waves,
- *          8 = one workgroup per (user, row block) instead of persistent workgroups.
- *          9 = small-output kernel (one wave per user; automatic when a user's block has few elements).
+ *          workgroups, non-temporal output stores); 9 = small-output kernel (one wave per user; automatic
+ *          when few subcarriers are selected).  Tuning knobs kept for A/B measurements: 3 = MFMA with plain
+ *          stores, 4 / 5 = 4- / 8-wave workgroups, 8 = one workgroup per (user, row block) instead of
+ *          persistent workgroups, 10 = 16-wave workgroups whatever the subcarrier count.
  */
 int dmx_channels_fd(const dmx_params* prm, const void* workspace, int64_t n_ue, int32_t n_paths_loaded,
                     int64_t user_begin, int64_t user_count, void* out_c64, int32_t variant, void* stream);
