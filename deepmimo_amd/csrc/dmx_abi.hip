@@ -109,7 +109,7 @@ int dmx_channels_fd(const dmx_params* prm, const void* workspace, int64_t n_ue, 
     if (rc) return rc;
     if (!prm->freq_domain) { set_error("dmx_channels_fd called with freq_domain = 0"); return DMX_ERR_ARG; }
     if (prm->rx_filter) { set_error("rx_filter = 1 is handled by dmx_channels_fd_lpf"); return DMX_ERR_ARG; }
-    if (variant < 0 || variant > 10) { set_error("unknown variant %d", variant); return DMX_ERR_ARG; }
+    if (variant < 0 || variant > 11) { set_error("unknown variant %d", variant); return DMX_ERR_ARG; }
     if (prm->n_selected == 0) return DMX_OK;
     return launch_channels_fd(*prm, ws, user_begin, user_count, (float2*)out_c64, variant, (hipStream_t)stream);
 }

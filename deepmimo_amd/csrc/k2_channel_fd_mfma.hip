@@ -518,28 +518,33 @@ bool fd_mfma_preferred(const dmx_params& prm, const WsView& ws) {
     return fd_mfma_supported(prm, ws) && M >= 24;
 }
 
-// persistent launches: as many workgroups as the device keeps resident at once (registers and LDS decide: ask the
-// runtime), each striding over the work items
-static int64_t resident_grid(const void* kfn, int threads, size_t smem, int64_t blocks) {
+// Persistent launches: workgroups stride over the work items.  Exactly as many workgroups as are resident at once
+// (registers and LDS decide: ask the runtime) is NOT the best grid: every CU then gets the same number of items and
+// the kernel ends with the slowest CU.  A few items per workgroup keep the amortised start-up and let the dispatcher
+// balance: at the headline shape 1 item per workgroup 18.6 ms, 390 (= resident grid) 18.3, 1.5 17.3, 3 16.9, 6 17.0,
+// 12 17.1, 24 17.4 (tools/ab_bench.py, one process, interleaved).
+static constexpr int ITEMS_PER_WG = 4;
+static int64_t resident_grid(const void* kfn, int threads, size_t smem, int64_t blocks, int items_per_wg) {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, threads, smem) != hipSuccess || per_cu < 1) {
         (void)hipGetLastError();
         per_cu = 1;
     }
-    const int64_t resident = (int64_t)256 * per_cu;
-    return blocks < resident ? blocks : resident;
+    int64_t grid = (int64_t)256 * per_cu;
+    if (items_per_wg > 0 && blocks / items_per_wg > grid) grid = blocks / items_per_wg;
+    return blocks < grid ? blocks : grid;
 }
 
 template <bool NT, int NW>
 static int launch_mfma_t(const WsView& ws, const MfmaArgs& a, int64_t blocks, size_t smem, float2* out, hipStream_t stream,
-                         bool persistent = true) {
+                         bool persistent = true, int items_per_wg = ITEMS_PER_WG) {
     const void* kfn = reinterpret_cast<const void*>(k2_fd_mfma<NT, NW>);
     if (smem > 64 * 1024) {     // per device and cheap: no cached flag, so every GPU of a process gets it
         hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, MFMA_LDS_MAX);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
     }
     int64_t grid = blocks;
-    if (persistent) grid = resident_grid(kfn, NW * 64, smem, blocks);
+    if (persistent) grid = resident_grid(kfn, NW * 64, smem, blocks, items_per_wg);
     hipLaunchKernelGGL((k2_fd_mfma<NT, NW>), dim3((unsigned)grid), dim3(NW * 64), smem, stream, ws, a, reinterpret_cast<float*>(out), blocks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("k2_fd_mfma launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
@@ -628,13 +633,14 @@ static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user
         case 3: return launch_mfma_t<true, 8>(ws, a, blocks, smem, out, stream);
         case 6: return launch_mfma_t<true, 16>(ws, a, blocks, smem, out, stream, false);     // one workgroup per work item
         case 8: return launch_mfma_t<true, 16>(ws, a, blocks, smem, out, stream);            // 16 waves whatever the strip count
+        case 9: return launch_mfma_t<true, 16>(ws, a, blocks, smem, out, stream, true, 0);   // exactly the resident workgroups
         case 0:
             // Registers (~125 VGPRs) hold this kernel to 4 waves per SIMD, i.e. ONE 16-wave workgroup per CU, whose
             // phases nothing overlaps.  With up to 8 strips (K <= 128) a wave per strip leaves waves idle anyway, and
             // 4-wave workgroups, two or three per CU overlapping each other, are 5-40 % faster (tools/ab_bench.py,
             // variants 10 vs 4: 3.29 -> 2.34 ms at 256 pairs x 16 subcarriers, 5.65 -> 5.34 at x 128; at x 512 the
             // 16-wave form wins 18.1 vs 19.2: there the stream of stores is the bound and more waves feed it).
-            if (nstrips <= 8) return launch_mfma_t<true, 4>(ws, a, blocks, smem, out, stream);
+            if (nstrips <= 8) return launch_mfma_t<true, 4>(ws, a, blocks, smem, out, stream, true, 0);   // small workgroups balance by themselves
             return launch_mfma_t<true, 16>(ws, a, blocks, smem, out, stream);
         default: set_error("unknown matrix-core kernel configuration %d", config); return DMX_ERR_ARG;
     }

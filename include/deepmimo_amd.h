@@ -129,7 +129,8 @@ int dmx_path_prep(const dmx_rays* rays, const dmx_params* prm, void* workspace, 
  *          workgroups, non-temporal output stores); 9 = small-output kernel (one wave per user; automatic
  *          when few subcarriers are selected).  Tuning knobs kept for A/B measurements: 3 = MFMA with plain
  *          stores, 4 / 5 = 4- / 8-wave workgroups, 8 = one workgroup per (user, row block) instead of
- *          persistent workgroups, 10 = 16-wave workgroups whatever the subcarrier count.
+ *          persistent workgroups, 10 = 16-wave workgroups whatever the subcarrier count, 11 = exactly the
+ *          resident number of persistent workgroups.
  */
 int dmx_channels_fd(const dmx_params* prm, const void* workspace, int64_t n_ue, int32_t n_paths_loaded,
                     int64_t user_begin, int64_t user_count, void* out_c64, int32_t variant, void* stream);
