@@ -132,28 +132,33 @@ __device__ __forceinline__ void gen_b_step(int s, const BLane& bl, int hh, int n
     }
 }
 
-// One 32-row tile of one strip: 8 ds_read_b128 of A', 12 MFMAs, 16 stores.
+// One 32-row tile of one strip: 2*NS ds_read_b128 of A' issued together, 3*NS MFMAs, 16 stores.  NS = K-steps that
+// hold a kept path (8 paths per step); a template parameter so that the body is one straight-line block - with the
+// steps guarded at run time every ds_read sat alone in its basic block in front of an `s_waitcnt lgkmcnt(0)`.
 // 32x32 accumulator: column on the lane, register i is row (i&3) + 8*(i>>2) + 4*(lane>>5).  Output through a
 // buffer descriptor over this workgroup's row block: the per-lane part of the address is one 32-bit voffset per
 // strip, the row of each store is a scalar soffset, and rows past the block end fall outside num_records and are
 // dropped by the hardware range check.
-template <bool NT>
-__device__ __forceinline__ void mfma_tile(int pt, const unsigned char* Ahi, const unsigned char* Alo, int col, int hh, int n_act,
+template <bool NT, int NS>
+__device__ __forceinline__ void mfma_tile(int pt, const unsigned char* Ahi, const unsigned char* Alo, int col, int hh,
                                           const h8 (&Bhi)[4], const h8 (&Blo)[4], const BLane& bl,
                                           __amdgpu_buffer_rsrc_t orsrc, unsigned row_bytes, float oscale) {
+    const size_t abase = (size_t)((pt << 5) + col) * ROW_BYTES + (size_t)hh * 16;
+    h8 ah[NS], al[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        ah[s] = *reinterpret_cast<const h8*>(Ahi + abase + s * 32);
+        al[s] = *reinterpret_cast<const h8*>(Alo + abase + s * 32);
+    }
+    __builtin_amdgcn_sched_barrier(0);          // keep the reads together in front: the scheduler otherwise sinks each to its use
     f16v acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const size_t abase = (size_t)((pt << 5) + col) * ROW_BYTES + (size_t)hh * 16;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        if (8 * s < n_act) {
-            const h8 ah = *reinterpret_cast<const h8*>(Ahi + abase + s * 32);
-            const h8 al = *reinterpret_cast<const h8*>(Alo + abase + s * 32);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bhi[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Blo[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bhi[s], acc, 0, 0, 0);
-        }
+    for (int s = 0; s < NS; ++s) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], Bhi[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], Blo[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], Bhi[s], acc, 0, 0, 0);
     }
     if (bl.kok) {
         const unsigned tile_off = (unsigned)(pt << 5) * row_bytes;
@@ -163,6 +168,14 @@ __device__ __forceinline__ void mfma_tile(int pt, const unsigned char* Ahi, cons
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[i] * oscale), orsrc, bl.lane_off, soff, NT ? 2 : 0);
         }
     }
+}
+
+template <bool NT, int NS>
+__device__ __forceinline__ void strip_tiles(int ntiles, const unsigned char* Ahi, const unsigned char* Alo, int col, int hh,
+                                            const h8 (&Bhi)[4], const h8 (&Blo)[4], const BLane& bl,
+                                            __amdgpu_buffer_rsrc_t orsrc, unsigned row_bytes, float oscale) {
+    for (int pt = 0; pt < ntiles; ++pt)
+        mfma_tile<NT, NS>(pt, Ahi, Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale);
 }
 
 // What one (user, row block) work item keeps in LDS: the A' hi / lo tiles and the per-user path tables.
@@ -309,8 +322,12 @@ __device__ __forceinline__ void consume_item(const WsView& ws, const MfmaArgs& a
         h8 Bhi[4], Blo[4];
 #pragma unroll
         for (int st = 0; st < 4; ++st) gen_b_step(st, bl, hh, n_act, L.qtab, L.crtab, L.citab, grow, a.K, gscale, Bhi[st], Blo[st]);
-        for (int pt = 0; pt < ntiles; ++pt)
-            mfma_tile<NT>(pt, L.Ahi, L.Alo, col, hh, n_act, Bhi, Blo, bl, orsrc, row_bytes, oscale);
+        switch ((n_act + 7) >> 3) {                                       // workgroup-uniform
+            case 1: strip_tiles<NT, 1>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
+            case 2: strip_tiles<NT, 2>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
+            case 3: strip_tiles<NT, 3>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
+            default: strip_tiles<NT, 4>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
+        }
     }
 }
 
