@@ -170,6 +170,38 @@ __device__ __forceinline__ void mfma_tile(int pt, const unsigned char* Ahi, cons
     }
 }
 
+// Same tile with the K-steps guarded at run time and one A' fragment live at a time: 28 fewer live registers.  The
+// grouped form above pushes the 128-VGPR kernel into spilling a few long-lived values, reloaded once per work item:
+// nothing against eight tiles per strip, +11-15 % on row blocks of one or two tiles (16 / 64 rows x 512 subcarriers:
+// 3.6 -> 4.0 and 5.5 -> 6.4 ms per 100k users).  GROUPED kernels are therefore only launched for >= 128-row blocks.
+template <bool NT>
+__device__ __forceinline__ void mfma_tile_rt(int pt, const unsigned char* Ahi, const unsigned char* Alo, int col, int hh, int n_act,
+                                             const h8 (&Bhi)[4], const h8 (&Blo)[4], const BLane& bl,
+                                             __amdgpu_buffer_rsrc_t orsrc, unsigned row_bytes, float oscale) {
+    f16v acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const size_t abase = (size_t)((pt << 5) + col) * ROW_BYTES + (size_t)hh * 16;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (8 * s < n_act) {
+            const h8 ah = *reinterpret_cast<const h8*>(Ahi + abase + s * 32);
+            const h8 al = *reinterpret_cast<const h8*>(Alo + abase + s * 32);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bhi[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Blo[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bhi[s], acc, 0, 0, 0);
+        }
+    }
+    if (bl.kok) {
+        const unsigned tile_off = (unsigned)(pt << 5) * row_bytes;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const unsigned soff = tile_off + (unsigned)((i & 3) + 8 * (i >> 2)) * row_bytes;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[i] * oscale), orsrc, bl.lane_off, soff, NT ? 2 : 0);
+        }
+    }
+}
+
 template <bool NT, int NS>
 __device__ __forceinline__ void strip_tiles(int ntiles, const unsigned char* Ahi, const unsigned char* Alo, int col, int hh,
                                             const h8 (&Bhi)[4], const h8 (&Blo)[4], const BLane& bl,
@@ -294,7 +326,7 @@ __device__ __forceinline__ void stage_item(const WsView& ws, const MfmaArgs& a, 
 // Stage 2 of a work item, after a barrier behind stage_item: a wave owns one 32-column strip at a time (B'
 // fragments in registers) and walks the row tiles with it, so the waves of the workgroup fill one 32-row band of the
 // user's block together and their stores stay within a few DRAM pages.  No barrier inside.
-template <bool NT, int NW>
+template <bool NT, int NW, bool GROUPED>
 __device__ __forceinline__ void consume_item(const WsView& ws, const MfmaArgs& a, float* __restrict__ out, int64_t work,
                                              const ItemLds& L) {
     constexpr int NTHR = NW * 64;
@@ -322,25 +354,30 @@ __device__ __forceinline__ void consume_item(const WsView& ws, const MfmaArgs& a
         h8 Bhi[4], Blo[4];
 #pragma unroll
         for (int st = 0; st < 4; ++st) gen_b_step(st, bl, hh, n_act, L.qtab, L.crtab, L.citab, grow, a.K, gscale, Bhi[st], Blo[st]);
-        switch ((n_act + 7) >> 3) {                                       // workgroup-uniform
-            case 1: strip_tiles<NT, 1>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
-            case 2: strip_tiles<NT, 2>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
-            case 3: strip_tiles<NT, 3>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
-            default: strip_tiles<NT, 4>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
+        if constexpr (GROUPED) {
+            switch ((n_act + 7) >> 3) {                                   // workgroup-uniform
+                case 1: strip_tiles<NT, 1>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
+                case 2: strip_tiles<NT, 2>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
+                case 3: strip_tiles<NT, 3>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
+                default: strip_tiles<NT, 4>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
+            }
+        } else {
+            for (int pt = 0; pt < ntiles; ++pt)
+                mfma_tile_rt<NT>(pt, L.Ahi, L.Alo, col, hh, n_act, Bhi, Blo, bl, orsrc, row_bytes, oscale);
         }
     }
 }
 
 // One (user, row block) per loop iteration.  Launched with one workgroup per work item, or persistently (grid =
 // what is resident at once, workgroups stride over the work items).
-template <bool NT, int NW>
+template <bool NT, int NW, bool GROUPED>
 __global__ __launch_bounds__(NW * 64) void k2_fd_mfma(WsView ws, MfmaArgs a, float* __restrict__ out, int64_t total) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ItemLds L = item_lds(smem, a.rows);
     for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
         stage_item<NW>(ws, a, w, L);
         __syncthreads();
-        consume_item<NT, NW>(ws, a, out, w, L);
+        consume_item<NT, NW, GROUPED>(ws, a, out, w, L);
         __syncthreads();                                                 // the next item's tiles overwrite these
     }
 }
@@ -552,17 +589,17 @@ static int64_t resident_grid(const void* kfn, int threads, size_t smem, int64_t 
     return blocks < grid ? blocks : grid;
 }
 
-template <bool NT, int NW>
+template <bool NT, int NW, bool GROUPED = false>
 static int launch_mfma_t(const WsView& ws, const MfmaArgs& a, int64_t blocks, size_t smem, float2* out, hipStream_t stream,
                          bool persistent = true, int items_per_wg = ITEMS_PER_WG) {
-    const void* kfn = reinterpret_cast<const void*>(k2_fd_mfma<NT, NW>);
+    const void* kfn = reinterpret_cast<const void*>(k2_fd_mfma<NT, NW, GROUPED>);
     if (smem > 64 * 1024) {     // per device and cheap: no cached flag, so every GPU of a process gets it
         hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, MFMA_LDS_MAX);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
     }
     int64_t grid = blocks;
     if (persistent) grid = resident_grid(kfn, NW * 64, smem, blocks, items_per_wg);
-    hipLaunchKernelGGL((k2_fd_mfma<NT, NW>), dim3((unsigned)grid), dim3(NW * 64), smem, stream, ws, a, reinterpret_cast<float*>(out), blocks);
+    hipLaunchKernelGGL((k2_fd_mfma<NT, NW, GROUPED>), dim3((unsigned)grid), dim3(NW * 64), smem, stream, ws, a, reinterpret_cast<float*>(out), blocks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("k2_fd_mfma launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
     return DMX_OK;
@@ -644,13 +681,19 @@ static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user
         set_error("%d selected subcarriers are too many for one 256-row block", a.K);
         return DMX_ERR_SHAPE;
     }
+    // 16-wave form: row blocks of >= 128 rows (>= 4 tiles per strip) take the grouped-read tile body, shorter ones the
+    // run-time-guarded one (see mfma_tile_rt)
+    auto go16 = [&](bool persistent, int items_per_wg) {
+        return a.rows >= 128 ? launch_mfma_t<true, 16, true>(ws, a, blocks, smem, out, stream, persistent, items_per_wg)
+                             : launch_mfma_t<true, 16, false>(ws, a, blocks, smem, out, stream, persistent, items_per_wg);
+    };
     switch (config) {
         case 1: return launch_mfma_t<false, 16>(ws, a, blocks, smem, out, stream);   // plain stores
         case 2: return launch_mfma_t<true, 4>(ws, a, blocks, smem, out, stream);
         case 3: return launch_mfma_t<true, 8>(ws, a, blocks, smem, out, stream);
-        case 6: return launch_mfma_t<true, 16>(ws, a, blocks, smem, out, stream, false);     // one workgroup per work item
-        case 8: return launch_mfma_t<true, 16>(ws, a, blocks, smem, out, stream);            // 16 waves whatever the strip count
-        case 9: return launch_mfma_t<true, 16>(ws, a, blocks, smem, out, stream, true, 0);   // exactly the resident workgroups
+        case 6: return go16(false, 0);                                               // one workgroup per work item
+        case 8: return go16(true, ITEMS_PER_WG);                                     // 16 waves whatever the strip count
+        case 9: return go16(true, 0);                                                // exactly the resident workgroups
         case 0:
             // Registers (~125 VGPRs) hold this kernel to 4 waves per SIMD, i.e. ONE 16-wave workgroup per CU, whose
             // phases nothing overlaps.  With up to 8 strips (K <= 128) a wave per strip leaves waves idle anyway, and
@@ -658,7 +701,7 @@ static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user
             // variants 10 vs 4: 3.29 -> 2.34 ms at 256 pairs x 16 subcarriers, 5.65 -> 5.34 at x 128; at x 512 the
             // 16-wave form wins 18.1 vs 19.2: there the stream of stores is the bound and more waves feed it).
             if (nstrips <= 8) return launch_mfma_t<true, 4>(ws, a, blocks, smem, out, stream, true, 0);   // small workgroups balance by themselves
-            return launch_mfma_t<true, 16>(ws, a, blocks, smem, out, stream);
+            return go16(true, ITEMS_PER_WG);
         default: set_error("unknown matrix-core kernel configuration %d", config); return DMX_ERR_ARG;
     }
 }
