@@ -299,7 +299,7 @@ def test_c_abi_argument_validation_without_gpu():
     assert lib.dmx_channels_fd(C.byref(p), C.c_void_p(base), 4, 5, 0, 4, C.c_void_p(base), 0, None) == -1 and "bandwidth" in err()
     p.bandwidth = 10e6
     assert lib.dmx_channels_fd(C.byref(p), C.c_void_p(base), 4, 5, 2, 4, C.c_void_p(base), 0, None) == -1 and "user range" in err()
-    assert lib.dmx_channels_fd(C.byref(p), C.c_void_p(base), 4, 5, 0, 4, C.c_void_p(base), 9, None) == -1 and "variant" in err()
+    assert lib.dmx_channels_fd(C.byref(p), C.c_void_p(base), 4, 5, 0, 4, C.c_void_p(base), 99, None) == -1 and "variant" in err()
     assert lib.dmx_channels_td(C.byref(p), C.c_void_p(base), 4, 5, 0, 4, C.c_void_p(base), None) == -1 and "freq_domain" in err()
     p.rx_filter = 1
     assert lib.dmx_channels_fd(C.byref(p), C.c_void_p(base), 4, 5, 0, 4, C.c_void_p(base), 0, None) == -1
