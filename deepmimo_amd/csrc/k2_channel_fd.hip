@@ -219,10 +219,13 @@ static int launch_valu_w(const WsView& ws, FdArgs a, int64_t user_count, float2*
 
 template <int LP, int RB, bool GLOAD = false>
 static int launch_valu(const WsView& ws, const FdArgs& a, int64_t user_count, float2* out, hipStream_t stream) {
-    // one wave per user when all subcarriers fit one 64-lane chunk and the panel is tiny (measured, 200k users,
-    // 25 paths: 8 pairs x 64 subcarriers 1.89 -> 1.33 ms; from 16 pairs on the four-wave form is as fast or faster)
+    // one wave per user (four users per workgroup, no workgroup barrier) for tiny panels, whatever the subcarrier
+    // count: measured, 200k users x 25 paths, 8 pairs: K=64 1.89 -> 1.33 ms, K=128 4.07 -> 2.14, K=256 4.79 -> 3.71,
+    // K=512 8.39 -> 6.95; 4 pairs x 256 3.36 -> 2.42.  From 9 pairs on the four-wave form (or the matrix cores) wins.
+    // (Turning the phasors from one 64-subcarrier chunk to the next by a per-path rotation instead of a fresh
+    // sin/cos was tried here: the kernel already spills at 256 VGPRs and the extra live state made it 2.4x slower.)
     const size_t need = (size_t)LP * 8 + (size_t)(a.m_rx + a.m_tx) * 2 * LP * 4;
-    if (a.K <= 64 && a.m_rx * a.m_tx <= 8 && need <= 16 * 1024 - 16)
+    if (a.m_rx * a.m_tx <= 8 && need <= 16 * 1024 - 16)
         return launch_valu_w<LP, RB, GLOAD, 1>(ws, a, user_count, out, stream);
     return launch_valu_w<LP, RB, GLOAD, 4>(ws, a, user_count, out, stream);
 }

@@ -564,12 +564,18 @@ bool fd_mfma_supported(const dmx_params& prm, const WsView& ws) {
     return prm.n_selected >= 1;
 }
 
-// automatic choice: the matrix-core kernel pays off once a 32-row tile is mostly full.  (Few subcarriers go to the
-// small-output kernel first, k2_channel_fd_small.hip; what is left of them here still beats the subcarrier-per-lane
-// kernel, which idles 64 - K lanes: 16 vs 79 ms at 1024 pairs x 2 subcarriers.)
+// Automatic choice against the subcarrier-per-lane vector kernel (few subcarriers go to the small-output kernel first,
+// k2_channel_fd_small.hip).  Measured, 200k users x 25 paths, ms for vector | matrix cores (tools/ab_bench.py):
+//   16 pairs: K=32 4.3 | 2.7, K=128 6.3 | 3.5, K=512 13.3 | 7.6        12 pairs: K=512 10.9 | 7.4     9 pairs: K=512 8.8 | 7.3
+//    8 pairs: K=64 1.3 | 2.8, K=256 3.7 | 5.2, K=512 6.9 | 7.3, K=1024 13.5 | 11.6           4 pairs: K=1024 8.4 | 11.5
+// The matrix-core time hardly depends on the pair count there (it is the B' generation), the vector kernel's is
+// proportional to pairs x subcarriers.
 bool fd_mfma_preferred(const dmx_params& prm, const WsView& ws) {
     const int M = prm.ue_shape[0] * prm.ue_shape[1] * prm.bs_shape[0] * prm.bs_shape[1];
-    return fd_mfma_supported(prm, ws) && M >= 24;
+    const int K = prm.n_selected;
+    if (!fd_mfma_supported(prm, ws)) return false;
+    if (M >= 9) return true;                  // 9 pairs x 64 subcarriers: 3.6 | 2.8
+    return M == 8 && K >= 1024;
 }
 
 // Persistent launches: workgroups stride over the work items.  Exactly as many workgroups as are resident at once
