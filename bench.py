@@ -276,6 +276,9 @@ def main():
                                f"({'random valid count' if args.random_valid else 'all valid'}) x {w['N']} subcarriers",
                    "users_total": total_users, "parallelism": f"user-shard x{world}",
                    "fd_kernel_variant": args.variant,
+                   "fd_kernel": {1: "k2_fd_valu", 2: "k2_fd_mfma", 9: "k2_fd_small"}.get(
+                       int(args.variant) if args.variant else
+                       eng.lib.dmx_fd_kernel_choice(C.byref(prep0.params_struct), prep0.n_paths_loaded), "k2_fd_mfma"),
                    "complex_macs_per_s": cmacs * world / (elapsed / max(args.steps, 1))},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, n_ue, args.variant),

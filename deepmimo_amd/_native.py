@@ -17,7 +17,7 @@ EXPORTED_SYMBOLS = ("dmx_version", "dmx_last_error", "dmx_workspace_bytes", "dmx
                     "dmx_path_prep", "dmx_channels_fd", "dmx_channels_td", "dmx_channels_fd_lpf",
                     "dmx_lpf_workspace_bytes", "dmx_mat5_find", "dmx_mat_to_rowmajor_f32",
                     "dmx_beam_workspace_bytes", "dmx_channels_fd_beams", "dmx_pathloss",
-                    "dmx_p2m_count_rx", "dmx_p2m_parse_paths")
+                    "dmx_p2m_count_rx", "dmx_p2m_parse_paths", "dmx_fd_kernel_choice")
 
 PATTERN_IDS = {"isotropic": 0, "halfwave-dipole": 1}
 
@@ -83,6 +83,8 @@ def load():
     lib.dmx_last_error.restype = C.c_char_p
     lib.dmx_workspace_bytes.restype = C.c_size_t
     lib.dmx_workspace_bytes.argtypes = [C.POINTER(DmxParams), C.c_int64, C.c_int32]
+    lib.dmx_fd_kernel_choice.restype = C.c_int
+    lib.dmx_fd_kernel_choice.argtypes = [C.POINTER(DmxParams), C.c_int32]
     lib.dmx_decode_max_delay.restype = C.c_float
     lib.dmx_decode_max_delay.argtypes = [C.c_uint32]
     lib.dmx_path_prep.restype = C.c_int

@@ -114,6 +114,15 @@ int dmx_channels_fd(const dmx_params* prm, const void* workspace, int64_t n_ue, 
     return launch_channels_fd(*prm, ws, user_begin, user_count, (float2*)out_c64, variant, (hipStream_t)stream);
 }
 
+int dmx_fd_kernel_choice(const dmx_params* prm, int32_t n_paths_loaded) {
+    if (!prm) { set_error("params is NULL"); return DMX_ERR_ARG; }
+    if (n_paths_loaded < 0 || prm->n_selected < 0 || prm->bs_shape[0] < 1 || prm->bs_shape[1] < 1 || prm->ue_shape[0] < 1 ||
+        prm->ue_shape[1] < 1) { set_error("bad shape"); return DMX_ERR_SHAPE; }
+    WsView ws{};
+    ws.P = used_paths(prm, n_paths_loaded);
+    return fd_auto_choice(*prm, ws);
+}
+
 size_t dmx_lpf_workspace_bytes(const dmx_params* prm, int64_t user_count, int32_t n_paths_loaded) {
     if (!prm || user_count < 0 || n_paths_loaded < 0 || prm->n_selected < 0) return 0;
     return align_up((size_t)user_count * (size_t)used_paths(prm, n_paths_loaded) * (size_t)prm->n_selected * 8, 256);

@@ -73,6 +73,7 @@ int launch_path_prep(const dmx_rays& rays, const dmx_params& prm, const WsView& 
                      hipStream_t stream);
 int launch_channels_fd(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
                        float2* out, int variant, hipStream_t stream);
+int fd_auto_choice(const dmx_params& prm, const WsView& ws);
 int launch_channels_fd_lpf(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
                            float2* gtab, float2* out, hipStream_t stream);
 int launch_channels_fd_beams(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,

@@ -283,6 +283,13 @@ int launch_channels_fd_small(const dmx_params& prm, const WsView& ws, int64_t us
                              float2* out, hipStream_t stream);
 bool fd_small_preferred(const dmx_params& prm, const WsView& ws);
 
+// what variant 0 runs for this shape: 9 small-output kernel, 2 matrix cores, 1 fp32 vector kernel
+int fd_auto_choice(const dmx_params& prm, const WsView& ws) {
+    if (fd_small_preferred(prm, ws)) return 9;
+    if (fd_mfma_preferred(prm, ws)) return 2;
+    return 1;
+}
+
 int launch_channels_fd(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
                        float2* out, int variant, hipStream_t stream) {
     if (user_count == 0) return DMX_OK;
@@ -291,9 +298,10 @@ int launch_channels_fd(const dmx_params& prm, const WsView& ws, int64_t user_beg
         return DMX_ERR_SHAPE;
     }
     int rc;
-    if (variant == 9 || (variant == 0 && fd_small_preferred(prm, ws)))
+    if (variant == 0) variant = fd_auto_choice(prm, ws);
+    if (variant == 9)
         rc = launch_channels_fd_small(prm, ws, user_begin, user_count, out, stream);
-    else if (variant >= 2 || (variant == 0 && fd_mfma_preferred(prm, ws)))
+    else if (variant >= 2)
         rc = launch_channels_fd_mfma(prm, ws, user_begin, user_count, out, variant >= 3 ? variant - 2 : 0, stream);
     else
         rc = launch_fd_valu_any(prm, ws, user_begin, user_count, nullptr, out, stream);

@@ -135,6 +135,10 @@ int dmx_path_prep(const dmx_rays* rays, const dmx_params* prm, void* workspace, 
 int dmx_channels_fd(const dmx_params* prm, const void* workspace, int64_t n_ue, int32_t n_paths_loaded,
                     int64_t user_begin, int64_t user_count, void* out_c64, int32_t variant, void* stream);
 
+/* Host-only: the kernel `variant = 0` selects for this shape (1, 2 or 9 above), from measured crossovers; negative on
+ * a bad argument.  No GPU involved. */
+int dmx_fd_kernel_choice(const dmx_params* prm, int32_t n_paths_loaded);
+
 /*
  * Stage 2, frequency domain with the receive low-pass filter (ofdm.rx_filter = 1; replaces
  * channel.py:166-168, 193-194): g[l,k] = sum_d c_l sinc(d - dn_l) exp(-j 2pi d sc_k / N) is first

@@ -354,3 +354,29 @@ def test_reference_patch_installs_on_the_real_reference():
         finally:
             with redirect_stdout(io.StringIO()):
                 dm.config("use_gpu", False)
+
+
+def test_fd_kernel_choice_follows_the_measured_crossovers():
+    """dmx_fd_kernel_choice (host-only): what variant 0 runs.  9 = one wave per user (few subcarriers - DeepMIMO's
+    default is one), 2 = matrix cores (from 9 antenna pairs on), 1 = subcarrier-per-lane vector kernel (tiny panels)."""
+    import ctypes as C
+    from deepmimo_amd import _native as n
+    lib = n.load()
+
+    def choice(bs, ue, K, L=25):
+        p = n.DmxParams()
+        p.bs_shape[0], p.bs_shape[1], p.ue_shape[0], p.ue_shape[1] = bs[0], bs[1], ue[0], ue[1]
+        p.num_paths, p.freq_domain, p.n_subcarriers, p.n_selected, p.bandwidth = L, 1, max(K, 1), K, 10e6
+        return lib.dmx_fd_kernel_choice(C.byref(p), L)
+
+    assert choice((8, 1), (1, 1), 1) == 9            # reference defaults: channel.py:33-63
+    assert choice((8, 8), (2, 2), 512) == 2          # headline
+    assert choice((8, 8), (1, 1), 8) == 9
+    assert choice((8, 8), (2, 2), 16) == 2           # 4096 outputs: matrix cores
+    assert choice((16, 16), (2, 2), 2) == 9          # tables need one wave per workgroup, still ahead at K <= 4
+    assert choice((16, 16), (1, 1), 8) == 2
+    assert choice((8, 1), (1, 1), 16) == 9 and choice((8, 1), (1, 1), 64) == 1 and choice((8, 1), (1, 1), 512) == 1
+    assert choice((8, 1), (1, 1), 1024) == 2
+    assert choice((3, 3), (1, 1), 64) == 2 and choice((4, 1), (1, 1), 1024) == 1
+    assert choice((64, 64), (1, 1), 1) == 2          # tables of 4096 antennas do not fit the LDS of the small kernel
+    assert lib.dmx_fd_kernel_choice(None, 5) == -1
