@@ -75,7 +75,7 @@ struct BLane {                      // what a lane knows about its column of the
     int kidx, c;                    // subcarrier index in the selection, re/im column
     bool kok;                       // column inside the selection
     unsigned lane_off;              // byte offset of (row 4h, this column) inside a 32-row tile of the output
-    double kk;                      // selected subcarrier number
+    float kl, kf;                   // selected subcarrier number: its low 12 bits (exact) and the whole (both as float)
 };
 
 __device__ __forceinline__ BLane b_lane(int strip, int col, int hh, size_t twoK, const int32_t* __restrict__ sc) {
@@ -84,12 +84,14 @@ __device__ __forceinline__ BLane b_lane(int strip, int col, int hh, size_t twoK,
     b.kidx = ncol >> 1; b.c = ncol & 1;
     b.kok = (size_t)ncol < twoK;
     b.lane_off = ((unsigned)(4 * hh) * (unsigned)twoK + (unsigned)ncol) * 4u;
-    b.kk = (double)(b.kok ? sc[b.kidx] : 0);
+    const int kki = b.kok ? sc[b.kidx] : 0;
+    b.kl = (float)(kki & 4095);
+    b.kf = (float)kki;
     return b;
 }
 
 // one K-step (8 paths) of the strip's B' fragments
-__device__ __forceinline__ void gen_b_step(int s, const BLane& bl, int hh, int n_act, const double* qtab, const float* crtab,
+__device__ __forceinline__ void gen_b_step(int s, const BLane& bl, int hh, int n_act, const float2* qtab, const float* crtab,
                                            const float* citab, const float2* __restrict__ grow, int K, float gs,
                                            h8& Bhi, h8& Blo) {
     Bhi = h8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -108,7 +110,12 @@ __device__ __forceinline__ void gen_b_step(int s, const BLane& bl, int hh, int n
             mr[t] = g.x * gs; mi[t] = g.y * gs;
         } else {
             float sn, cs;
-            sincos_rev(frac_rev(qtab[pl] * bl.kk), sn, cs);
+            // Phase dn_l sc_k / N in revolutions without float64: q = dn/N is held as qh + ql with qh a multiple of
+            // 2^-12 in [0, 1], so qh * (k mod 4096) is exact in float32 and qh * (k - k mod 4096) is an integer
+            // (drops out); ql <= 2^-13 carries the rest (its product is rounded at 2^-24 of a value below one).
+            const float2 q = qtab[pl];
+            const float p1 = q.x * bl.kl;
+            sincos_rev(fmaf(q.y, bl.kf, p1 - rintf(p1)), sn, cs);
             const float cr = crtab[pl], ci = citab[pl];
             mr[t] = cr * cs + ci * sn;                                  // Re c*exp(-j x)
             mi[t] = ci * cs - cr * sn;                                  // Im
@@ -214,7 +221,7 @@ __device__ __forceinline__ void strip_tiles(int ntiles, const unsigned char* Ahi
 struct ItemLds {
     unsigned char* Ahi;      // [rows][144 B]
     unsigned char* Alo;
-    double* qtab;            // [32] dn_l / N
+    float2* qtab;            // [32] dn_l / N as (multiple of 2^-12, remainder)
     float* crtab;            // [32] scaled c_l
     float* citab;
     float* misc;             // [4]  per-user output / operand scales
@@ -224,7 +231,7 @@ __device__ __forceinline__ ItemLds item_lds(unsigned char* base, int rows) {
     ItemLds L;
     L.Ahi = base;
     L.Alo = base + (size_t)rows * ROW_BYTES;
-    L.qtab = reinterpret_cast<double*>(base + (size_t)2 * rows * ROW_BYTES);
+    L.qtab = reinterpret_cast<float2*>(base + (size_t)2 * rows * ROW_BYTES);
     L.crtab = reinterpret_cast<float*>(L.qtab + LPAD);
     L.citab = L.crtab + LPAD;
     L.misc = L.citab + LPAD;
@@ -270,7 +277,9 @@ __device__ __forceinline__ void stage_item(const WsView& ws, const MfmaArgs& a, 
         const float gs = ldexpf(1.0f, 10 - e);
         if (lane < LPAD) {
             const bool ok = lane < n_act;
-            L.qtab[lane] = ok ? (double)ws.dn[rb + lane] * a.inv_n : 0.0;
+            const double q = ok ? (double)ws.dn[rb + lane] * a.inv_n : 0.0;
+            const double qh = rint(q * 4096.0) * (1.0 / 4096.0);
+            L.qtab[lane] = make_float2((float)qh, (float)(q - qh));
             L.crtab[lane] = ok ? ws.c_re[rb + lane] * gs : 0.f;
             L.citab[lane] = ok ? ws.c_im[rb + lane] * gs : 0.f;
         }
