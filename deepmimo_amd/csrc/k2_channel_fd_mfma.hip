@@ -180,7 +180,7 @@ __device__ __forceinline__ void mfma_tile(int pt, const unsigned char* Ahi, cons
 // Same tile with the K-steps guarded at run time and one A' fragment live at a time: 28 fewer live registers.  The
 // grouped form above pushes the 128-VGPR kernel into spilling a few long-lived values, reloaded once per work item:
 // nothing against eight tiles per strip, +11-15 % on row blocks of one or two tiles (16 / 64 rows x 512 subcarriers:
-// 3.6 -> 4.0 and 5.5 -> 6.4 ms per 100k users).  GROUPED kernels are therefore only launched for >= 128-row blocks.
+// 3.6 -> 4.0 and 5.5 -> 6.4 ms per 100k users).  The grouped and pipelined kernels (MODE 1, 2) are therefore only launched for >= 128-row blocks.
 template <bool NT>
 __device__ __forceinline__ void mfma_tile_rt(int pt, const unsigned char* Ahi, const unsigned char* Alo, int col, int hh, int n_act,
                                              const h8 (&Bhi)[4], const h8 (&Blo)[4], const BLane& bl,
@@ -209,12 +209,82 @@ __device__ __forceinline__ void mfma_tile_rt(int pt, const unsigned char* Ahi, c
     }
 }
 
-template <bool NT, int NS>
+// Software-pipelined strip: the matrix-core chain of tile t + 1 is issued with the scale-and-store of tile t threaded
+// between its instructions (two accumulators).  A wave otherwise emits its 16 stores in one burst after a ~400-cycle
+// chain during which it stores nothing; with 4 waves per SIMD those bursts leave the memory pipeline idle in between.
+template <bool NT, int I0, int I1>
+__device__ __forceinline__ void store_rows(const f16v& acc, float oscale, const BLane& bl, __amdgpu_buffer_rsrc_t orsrc,
+                                           unsigned tile_off, unsigned row_bytes) {
+    if (!bl.kok) return;
+#pragma unroll
+    for (int i = I0; i < I1; ++i) {
+        const unsigned soff = tile_off + (unsigned)((i & 3) + 8 * (i >> 2)) * row_bytes;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[i] * oscale), orsrc, bl.lane_off, soff, NT ? 2 : 0);
+    }
+}
+
+// chain of tile `pt` into a fresh accumulator while `prev` (tile pt - 1) is stored, a few rows after every K-step
+template <bool NT, int NS, bool STORE_PREV>
+__device__ __forceinline__ f16v chain_tile(int pt, const f16v& prev, const unsigned char* Ahi, const unsigned char* Alo, int col, int hh,
+                                           const h8 (&Bhi)[4], const h8 (&Blo)[4], const BLane& bl,
+                                           __amdgpu_buffer_rsrc_t orsrc, unsigned row_bytes, float oscale) {
+    const size_t abase = (size_t)((pt << 5) + col) * ROW_BYTES + (size_t)hh * 16;
+    const unsigned prev_off = (unsigned)((pt - 1) << 5) * row_bytes;
+    f16v acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const h8 ah = *reinterpret_cast<const h8*>(Ahi + abase + s * 32);
+        const h8 al = *reinterpret_cast<const h8*>(Alo + abase + s * 32);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bhi[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Blo[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bhi[s], acc, 0, 0, 0);
+        if constexpr (STORE_PREV) {
+            // 16 rows over NS K-steps
+            if constexpr (NS == 4) {
+                if (s == 0) store_rows<NT, 0, 4>(prev, oscale, bl, orsrc, prev_off, row_bytes);
+                if (s == 1) store_rows<NT, 4, 8>(prev, oscale, bl, orsrc, prev_off, row_bytes);
+                if (s == 2) store_rows<NT, 8, 12>(prev, oscale, bl, orsrc, prev_off, row_bytes);
+                if (s == 3) store_rows<NT, 12, 16>(prev, oscale, bl, orsrc, prev_off, row_bytes);
+            } else if constexpr (NS == 3) {
+                if (s == 0) store_rows<NT, 0, 6>(prev, oscale, bl, orsrc, prev_off, row_bytes);
+                if (s == 1) store_rows<NT, 6, 11>(prev, oscale, bl, orsrc, prev_off, row_bytes);
+                if (s == 2) store_rows<NT, 11, 16>(prev, oscale, bl, orsrc, prev_off, row_bytes);
+            } else if constexpr (NS == 2) {
+                if (s == 0) store_rows<NT, 0, 8>(prev, oscale, bl, orsrc, prev_off, row_bytes);
+                if (s == 1) store_rows<NT, 8, 16>(prev, oscale, bl, orsrc, prev_off, row_bytes);
+            } else {
+                store_rows<NT, 0, 16>(prev, oscale, bl, orsrc, prev_off, row_bytes);
+            }
+            __builtin_amdgcn_sched_barrier(0);       // keep this K-step's stores behind its MFMAs and in front of the next reads
+        }
+    }
+    return acc;
+}
+
+template <bool NT, int NS, bool PIPE>
 __device__ __forceinline__ void strip_tiles(int ntiles, const unsigned char* Ahi, const unsigned char* Alo, int col, int hh,
                                             const h8 (&Bhi)[4], const h8 (&Blo)[4], const BLane& bl,
                                             __amdgpu_buffer_rsrc_t orsrc, unsigned row_bytes, float oscale) {
-    for (int pt = 0; pt < ntiles; ++pt)
-        mfma_tile<NT, NS>(pt, Ahi, Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale);
+    if constexpr (!PIPE) {
+        for (int pt = 0; pt < ntiles; ++pt)
+            mfma_tile<NT, NS>(pt, Ahi, Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale);
+        return;
+    }
+    f16v a0 = {};
+    a0 = chain_tile<NT, NS, false>(0, a0, Ahi, Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale);
+    int pt = 1;
+    for (; pt + 1 < ntiles; pt += 2) {                                   // a0 holds tile pt - 1
+        const f16v a1 = chain_tile<NT, NS, true>(pt, a0, Ahi, Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale);
+        a0 = chain_tile<NT, NS, true>(pt + 1, a1, Ahi, Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale);
+    }
+    if (pt < ntiles) {
+        const f16v a1 = chain_tile<NT, NS, true>(pt, a0, Ahi, Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale);
+        store_rows<NT, 0, 16>(a1, oscale, bl, orsrc, (unsigned)(pt << 5) * row_bytes, row_bytes);
+    } else {
+        store_rows<NT, 0, 16>(a0, oscale, bl, orsrc, (unsigned)((ntiles - 1) << 5) * row_bytes, row_bytes);
+    }
 }
 
 // What one (user, row block) work item keeps in LDS: the A' hi / lo tiles and the per-user path tables.
@@ -335,7 +405,7 @@ __device__ __forceinline__ void stage_item(const WsView& ws, const MfmaArgs& a, 
 // Stage 2 of a work item, after a barrier behind stage_item: a wave owns one 32-column strip at a time (B'
 // fragments in registers) and walks the row tiles with it, so the waves of the workgroup fill one 32-row band of the
 // user's block together and their stores stay within a few DRAM pages.  No barrier inside.
-template <bool NT, int NW, bool GROUPED>
+template <bool NT, int NW, int MODE>
 __device__ __forceinline__ void consume_item(const WsView& ws, const MfmaArgs& a, float* __restrict__ out, int64_t work,
                                              const ItemLds& L) {
     constexpr int NTHR = NW * 64;
@@ -363,12 +433,13 @@ __device__ __forceinline__ void consume_item(const WsView& ws, const MfmaArgs& a
         h8 Bhi[4], Blo[4];
 #pragma unroll
         for (int st = 0; st < 4; ++st) gen_b_step(st, bl, hh, n_act, L.qtab, L.crtab, L.citab, grow, a.K, gscale, Bhi[st], Blo[st]);
-        if constexpr (GROUPED) {
+        if constexpr (MODE != 0) {
+            constexpr bool PIPE = MODE == 2;
             switch ((n_act + 7) >> 3) {                                   // workgroup-uniform
-                case 1: strip_tiles<NT, 1>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
-                case 2: strip_tiles<NT, 2>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
-                case 3: strip_tiles<NT, 3>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
-                default: strip_tiles<NT, 4>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
+                case 1: strip_tiles<NT, 1, PIPE>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
+                case 2: strip_tiles<NT, 2, PIPE>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
+                case 3: strip_tiles<NT, 3, PIPE>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
+                default: strip_tiles<NT, 4, PIPE>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
             }
         } else {
             for (int pt = 0; pt < ntiles; ++pt)
@@ -379,14 +450,14 @@ __device__ __forceinline__ void consume_item(const WsView& ws, const MfmaArgs& a
 
 // One (user, row block) per loop iteration.  Launched with one workgroup per work item, or persistently (grid =
 // what is resident at once, workgroups stride over the work items).
-template <bool NT, int NW, bool GROUPED>
+template <bool NT, int NW, int MODE>
 __global__ __launch_bounds__(NW * 64) void k2_fd_mfma(WsView ws, MfmaArgs a, float* __restrict__ out, int64_t total) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ItemLds L = item_lds(smem, a.rows);
     for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
         stage_item<NW>(ws, a, w, L);
         __syncthreads();
-        consume_item<NT, NW, GROUPED>(ws, a, out, w, L);
+        consume_item<NT, NW, MODE>(ws, a, out, w, L);
         __syncthreads();                                                 // the next item's tiles overwrite these
     }
 }
@@ -604,17 +675,17 @@ static int64_t resident_grid(const void* kfn, int threads, size_t smem, int64_t 
     return blocks < grid ? blocks : grid;
 }
 
-template <bool NT, int NW, bool GROUPED = false>
+template <bool NT, int NW, int MODE = 0>
 static int launch_mfma_t(const WsView& ws, const MfmaArgs& a, int64_t blocks, size_t smem, float2* out, hipStream_t stream,
                          bool persistent = true, int items_per_wg = ITEMS_PER_WG) {
-    const void* kfn = reinterpret_cast<const void*>(k2_fd_mfma<NT, NW, GROUPED>);
+    const void* kfn = reinterpret_cast<const void*>(k2_fd_mfma<NT, NW, MODE>);
     if (smem > 64 * 1024) {     // per device and cheap: no cached flag, so every GPU of a process gets it
         hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, MFMA_LDS_MAX);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
     }
     int64_t grid = blocks;
     if (persistent) grid = resident_grid(kfn, NW * 64, smem, blocks, items_per_wg);
-    hipLaunchKernelGGL((k2_fd_mfma<NT, NW, GROUPED>), dim3((unsigned)grid), dim3(NW * 64), smem, stream, ws, a, reinterpret_cast<float*>(out), blocks);
+    hipLaunchKernelGGL((k2_fd_mfma<NT, NW, MODE>), dim3((unsigned)grid), dim3(NW * 64), smem, stream, ws, a, reinterpret_cast<float*>(out), blocks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("k2_fd_mfma launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
     return DMX_OK;
@@ -696,11 +767,16 @@ static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user
         set_error("%d selected subcarriers are too many for one 256-row block", a.K);
         return DMX_ERR_SHAPE;
     }
-    // 16-wave form: row blocks of >= 128 rows (>= 4 tiles per strip) take the grouped-read tile body, shorter ones the
-    // run-time-guarded one (see mfma_tile_rt)
+    // 16-wave form, three tile-loop bodies (separate kernels: together in one they spill inside the loops):
+    //   MODE 0  fewer than 128 rows per block (< 4 tiles per strip): run-time-guarded tile, no spills (mfma_tile_rt)
+    //   MODE 1  >= 128 rows, at most 16 path slots: grouped reads, plain loop
+    //   MODE 2  >= 128 rows, more than 16 path slots (long MFMA chains): software-pipelined strip - 16.7 vs 17.5 ms at
+    //           the headline shape, 15.1 vs 16.5 with random path counts; with 10 path slots (config 2 x 200k users)
+    //           the short chains make it 9.5 vs 8.6 ms, hence MODE 1 there
     auto go16 = [&](bool persistent, int items_per_wg) {
-        return a.rows >= 128 ? launch_mfma_t<true, 16, true>(ws, a, blocks, smem, out, stream, persistent, items_per_wg)
-                             : launch_mfma_t<true, 16, false>(ws, a, blocks, smem, out, stream, persistent, items_per_wg);
+        if (a.rows < 128) return launch_mfma_t<true, 16, 0>(ws, a, blocks, smem, out, stream, persistent, items_per_wg);
+        if (ws.P <= 16) return launch_mfma_t<true, 16, 1>(ws, a, blocks, smem, out, stream, persistent, items_per_wg);
+        return launch_mfma_t<true, 16, 2>(ws, a, blocks, smem, out, stream, persistent, items_per_wg);
     };
     switch (config) {
         case 1: return launch_mfma_t<false, 16>(ws, a, blocks, smem, out, stream);   // plain stores
