@@ -455,7 +455,7 @@ __device__ __forceinline__ void consume_item(const WsView& ws, const MfmaArgs& a
 // One (user, row block) per loop iteration.  Launched with one workgroup per work item, or persistently (grid =
 // what is resident at once, workgroups stride over the work items).
 template <bool NT, int NW, int MODE>
-__global__ __launch_bounds__(NW * 64) void k2_fd_mfma(WsView ws, MfmaArgs a, float* __restrict__ out, int64_t total) {
+__global__ __launch_bounds__(NW * 64, 4) void k2_fd_mfma(WsView ws, MfmaArgs a, float* __restrict__ out, int64_t total) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ItemLds L = item_lds(smem, a.rows);
     for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
@@ -782,10 +782,18 @@ static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user
         if (ws.P <= 16) return launch_mfma_t<true, 16, 1>(ws, a, blocks, smem, out, stream, persistent, items_per_wg);
         return launch_mfma_t<true, 16, 2>(ws, a, blocks, smem, out, stream, persistent, items_per_wg);
     };
+    // The same three bodies in 8-wave workgroups.  Every kernel here is compiled for 4 waves per SIMD (128 VGPRs); a
+    // 16-wave workgroup then fills a CU alone, while two 8-wave workgroups share it and overlap each other's phases:
+    // 16.0 vs 16.8 ms at the headline shape, 31.7 vs 32.5 at config 5, 8.3 vs 8.8 at config 2 x 200k users.
+    auto go8 = [&](bool persistent, int items_per_wg) {
+        if (a.rows < 128) return launch_mfma_t<true, 8, 0>(ws, a, blocks, smem, out, stream, persistent, items_per_wg);
+        if (ws.P <= 16) return launch_mfma_t<true, 8, 1>(ws, a, blocks, smem, out, stream, persistent, items_per_wg);
+        return launch_mfma_t<true, 8, 2>(ws, a, blocks, smem, out, stream, persistent, items_per_wg);
+    };
     switch (config) {
         case 1: return launch_mfma_t<false, 16>(ws, a, blocks, smem, out, stream);   // plain stores
         case 2: return launch_mfma_t<true, 4>(ws, a, blocks, smem, out, stream);
-        case 3: return launch_mfma_t<true, 8>(ws, a, blocks, smem, out, stream);
+        case 3: return go8(true, ITEMS_PER_WG);                                      // 8 waves whatever the strip count
         case 6: return go16(false, 0);                                               // one workgroup per work item
         case 8: return go16(true, ITEMS_PER_WG);                                     // 16 waves whatever the strip count
         case 9: return go16(true, 0);                                                // exactly the resident workgroups
@@ -796,7 +804,7 @@ static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user
             // variants 10 vs 4: 3.29 -> 2.34 ms at 256 pairs x 16 subcarriers, 5.65 -> 5.34 at x 128; at x 512 the
             // 16-wave form wins 18.1 vs 19.2: there the stream of stores is the bound and more waves feed it).
             if (nstrips <= 8) return launch_mfma_t<true, 4>(ws, a, blocks, smem, out, stream, true, 0);   // small workgroups balance by themselves
-            return go16(true, ITEMS_PER_WG);
+            return go8(true, ITEMS_PER_WG);
         default: set_error("unknown matrix-core kernel configuration %d", config); return DMX_ERR_ARG;
     }
 }
