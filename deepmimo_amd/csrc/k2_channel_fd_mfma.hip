@@ -668,6 +668,7 @@ bool fd_mfma_preferred(const dmx_params& prm, const WsView& ws) {
 // balance: at the headline shape 1 item per workgroup 18.6 ms, 390 (= resident grid) 18.3, 1.5 17.3, 3 16.9, 6 17.0,
 // 12 17.1, 24 17.4 (tools/ab_bench.py, one process, interleaved).
 static constexpr int ITEMS_PER_WG = 4;
+static constexpr int ITEMS_PER_WG8 = 8;     // 8-wave workgroups: 0 (resident grid) 17.3 ms, 2 17.2, 4 16.4, 8 16.4, 16 16.5; config 5: 32.8, 32.8, 32.3, 31.2, 31.7
 static int64_t resident_grid(const void* kfn, int threads, size_t smem, int64_t blocks, int items_per_wg) {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, threads, smem) != hipSuccess || per_cu < 1) {
@@ -675,7 +676,13 @@ static int64_t resident_grid(const void* kfn, int threads, size_t smem, int64_t 
         per_cu = 1;
     }
     int64_t grid = (int64_t)256 * per_cu;
-    if (items_per_wg > 0 && blocks / items_per_wg > grid) grid = blocks / items_per_wg;
+    if (items_per_wg > 0) {
+        // a few items per workgroup, but never fewer than four grids' worth of workgroups when the work allows it
+        // (config 2 = 10k items: 0.43 ms with 2500 workgroups, 0.48 with 1250)
+        int64_t g = blocks / items_per_wg;
+        if (g < 4 * grid) g = blocks < 4 * grid ? blocks : 4 * grid;
+        if (g > grid) grid = g;
+    }
     return blocks < grid ? blocks : grid;
 }
 
@@ -793,7 +800,7 @@ static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user
     switch (config) {
         case 1: return launch_mfma_t<false, 16>(ws, a, blocks, smem, out, stream);   // plain stores
         case 2: return launch_mfma_t<true, 4>(ws, a, blocks, smem, out, stream);
-        case 3: return go8(true, ITEMS_PER_WG);                                      // 8 waves whatever the strip count
+        case 3: return go8(true, ITEMS_PER_WG8);                                     // 8 waves whatever the strip count
         case 6: return go16(false, 0);                                               // one workgroup per work item
         case 8: return go16(true, ITEMS_PER_WG);                                     // 16 waves whatever the strip count
         case 9: return go16(true, 0);                                                // exactly the resident workgroups
@@ -804,7 +811,7 @@ static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user
             // variants 10 vs 4: 3.29 -> 2.34 ms at 256 pairs x 16 subcarriers, 5.65 -> 5.34 at x 128; at x 512 the
             // 16-wave form wins 18.1 vs 19.2: there the stream of stores is the bound and more waves feed it).
             if (nstrips <= 8) return launch_mfma_t<true, 4>(ws, a, blocks, smem, out, stream, true, 0);   // small workgroups balance by themselves
-            return go8(true, ITEMS_PER_WG);
+            return go8(true, ITEMS_PER_WG8);
         default: set_error("unknown matrix-core kernel configuration %d", config); return DMX_ERR_ARG;
     }
 }

@@ -125,12 +125,12 @@ int dmx_path_prep(const dmx_rays* rays, const dmx_params* prm, void* workspace, 
  * channel.py:264-284): out[u, rx, tx, k] = sum_l a_rx[rx,l] a_tx[tx,l] c_l exp(-j 2pi dn_l sc_k / N)
  * for users [user_begin, user_begin + user_count) of the prepared workspace; `out` points at the
  * first of those users (complex64 [user_count, M_rx, M_tx, K]).
- * variant: 0 = automatic; 1 = fp32 vector kernel; 2 = split-precision MFMA kernel (persistent 16-wave
- *          workgroups, non-temporal output stores); 9 = small-output kernel (one wave per user; automatic
- *          when few subcarriers are selected).  Tuning knobs kept for A/B measurements: 3 = MFMA with plain
- *          stores, 4 / 5 = 4- / 8-wave workgroups, 8 = one workgroup per (user, row block) instead of
- *          persistent workgroups, 10 = 16-wave workgroups whatever the subcarrier count, 11 = exactly the
- *          resident number of persistent workgroups.
+ * variant: 0 = automatic; 1 = fp32 vector kernel; 2 = split-precision MFMA kernel (persistent workgroups of 8
+ *          waves, two per CU, or of 4 waves up to 128 subcarriers; non-temporal output stores); 9 = small-output
+ *          kernel (one wave per user; automatic when few subcarriers are selected).  Tuning knobs kept for A/B
+ *          measurements: 3 = MFMA with plain stores (16 waves), 4 / 5 / 10 = 4- / 8- / 16-wave workgroups whatever
+ *          the subcarrier count, 8 = one 16-wave workgroup per (user, row block) instead of persistent workgroups,
+ *          11 = exactly the resident number of persistent 16-wave workgroups.
  */
 int dmx_channels_fd(const dmx_params* prm, const void* workspace, int64_t n_ue, int32_t n_paths_loaded,
                     int64_t user_begin, int64_t user_count, void* out_c64, int32_t variant, void* stream);
