@@ -805,12 +805,11 @@ static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user
         case 8: return go16(true, ITEMS_PER_WG);                                     // 16 waves whatever the strip count
         case 9: return go16(true, 0);                                                // exactly the resident workgroups
         case 0:
-            // Registers (~125 VGPRs) hold this kernel to 4 waves per SIMD, i.e. ONE 16-wave workgroup per CU, whose
-            // phases nothing overlaps.  With up to 8 strips (K <= 128) a wave per strip leaves waves idle anyway, and
-            // 4-wave workgroups, two or three per CU overlapping each other, are 5-40 % faster (tools/ab_bench.py,
-            // variants 10 vs 4: 3.29 -> 2.34 ms at 256 pairs x 16 subcarriers, 5.65 -> 5.34 at x 128; at x 512 the
-            // 16-wave form wins 18.1 vs 19.2: there the stream of stores is the bound and more waves feed it).
-            if (nstrips <= 8) return launch_mfma_t<true, 4>(ws, a, blocks, smem, out, stream, true, 0);   // small workgroups balance by themselves
+            // 4-wave workgroups where little work shares a set of A' tiles - at most 8 strips (K <= 128) on fewer than
+            // 128 rows: 64 pairs x 32 subcarriers 1.12 vs 1.68 ms with 8 waves, 16 x 64: 1.08 vs 1.61.  From 128 rows
+            // on the 8-wave form wins at every strip count (256 pairs: K=16 2.10 vs 2.40, K=64 3.00 vs 3.39, K=128
+            // 4.68 vs 5.09, K=256 8.38 vs 9.07; a single 16-wave workgroup per CU is behind both everywhere).
+            if (nstrips <= 8 && a.rows < 128) return launch_mfma_t<true, 4>(ws, a, blocks, smem, out, stream, true, 0);
             return go8(true, ITEMS_PER_WG8);
         default: set_error("unknown matrix-core kernel configuration %d", config); return DMX_ERR_ARG;
     }
