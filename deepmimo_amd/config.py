@@ -18,7 +18,7 @@ class _Config:
         "gpu_device_id": 0,
         "scenarios_folder": "deepmimo_scenarios",
         "channel_output": "numpy",
-        "fd_kernel_variant": 0,      # 0 auto, 1 fp32 vector kernel, 2 split-precision MFMA kernel
+        "fd_kernel_variant": 0,      # 0 auto, 1 fp32 vector kernel, 2 split-precision MFMA kernel, 9 small-output kernel
     }
 
     def __init__(self):
