@@ -70,12 +70,23 @@ __global__ __launch_bounds__(256) void k4_td_tab(WsView ws, TdArgs a, float2* __
         brx[i] = v;                                         // the two tables are contiguous
     }
     __syncthreads();
-    for (size_t i = threadIdx.x; i < per_user; i += 256) {
-        const int s = (int)(i % P);
-        const int m = (int)((i / P) % a.m_tx);
-        const int r = (int)(i / ((size_t)P * a.m_tx));
-        const float2 b = brx[r * P + s], t = atx[m * P + s];
+    // thread = output element, 256 apart per step; (slot s, transmit element m, receive element r) of element i are
+    // advanced incrementally - three 64-bit divisions per element were most of this kernel's instructions
+    const unsigned tid = threadIdx.x;
+    unsigned sidx = tid % (unsigned)P, q = tid / (unsigned)P;               // q = r * m_tx + m
+    unsigned m = q % (unsigned)a.m_tx, r = q / (unsigned)a.m_tx;
+    const unsigned ds = 256u % (unsigned)P, dq = 256u / (unsigned)P;
+    const unsigned dm = dq % (unsigned)a.m_tx, dr = dq / (unsigned)a.m_tx;
+    for (size_t i = tid; i < per_user; i += 256) {
+        const float2 b = brx[r * P + sidx], t = atx[m * P + sidx];
         o[i] = make_float2(b.x * t.x - b.y * t.y, b.x * t.y + b.y * t.x);
+        sidx += ds;
+        unsigned carry = 0;
+        if (sidx >= (unsigned)P) { sidx -= (unsigned)P; carry = 1; }
+        m += dm + carry;
+        r += dr;
+        if (m >= (unsigned)a.m_tx) { m -= (unsigned)a.m_tx; ++r; }
+        if (m >= (unsigned)a.m_tx) { m -= (unsigned)a.m_tx; ++r; }       // dm + carry can reach m_tx
     }
 }
 
