@@ -237,11 +237,9 @@ __device__ __forceinline__ f16v chain_tile(int pt, const f16v& prev, const unsig
     h8 al = *reinterpret_cast<const h8*>(Alo + abase);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        __builtin_amdgcn_s_setprio(2);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bhi[s], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Blo[s], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bhi[s], acc, 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
         if (s + 1 < NS) {                      // next K-step's fragments: the read latency passes behind the stores below
             ah = *reinterpret_cast<const h8*>(Ahi + abase + (s + 1) * 32);
             al = *reinterpret_cast<const h8*>(Alo + abase + (s + 1) * 32);
