@@ -134,6 +134,8 @@ SHAPES = [
     (11, 9, [6, 4], [2, 1], 80, list(range(2, 68, 2)), {}),                   # 48 rows, odd K = 33 on the MFMA kernel
     (7, 5, [8, 4], [1, 1], 64, [5], {}),                                      # a single subcarrier
     (6, 4, [3, 3], [3, 3], 32, [31, -1, 32, 95], {}),                         # indices outside 0..N-1 are plain integers
+    (5, 25, [8, 4], [1, 1], 8192, list(range(3, 8192, 13)), dict(max_delay=700e-6)),   # subcarrier numbers beyond 4095 (two-term phase reduction)
+    (4, 25, [8, 8], [2, 2], 4096, list(range(4096)), dict(all_valid=True, max_delay=150e-6)),   # 4096 subcarriers: 32-KiB rows
 ]
 
 
