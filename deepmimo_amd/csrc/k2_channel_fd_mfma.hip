@@ -339,23 +339,31 @@ __device__ __forceinline__ void stage_item(const WsView& ws, const MfmaArgs& a, 
     const ItemPos ip = item_pos(ws, a, work);
     const int n_act = ip.n_act;
     if (n_act == 0) return;                                              // consume_item writes zeros, reads nothing
-    const size_t rb = ip.rb;
+    // uniform per-item bases and 32-bit path indices: indexed as array[row base + l] the compiler keeps eight 64-bit
+    // per-lane offsets alive across the whole item loop (16 VGPRs the tile loops need)
+    const float* __restrict__ c_re = ws.c_re + ip.rb;
+    const float* __restrict__ c_im = ws.c_im + ip.rb;
+    const float* __restrict__ dnp = ws.dn + ip.rb;
+    const double* __restrict__ rx_y = ws.rx_y + ip.rb;
+    const double* __restrict__ rx_z = ws.rx_z + ip.rb;
+    const double* __restrict__ tx_y = ws.tx_y + ip.rb;
+    const double* __restrict__ tx_z = ws.tx_z + ip.rb;
 
     // per-user power-of-two scale: max |c_l| component -> [512, 1024)
     if (wave == 0) {
         float m = 0.f;
-        if (lane < n_act) m = fmaxf(fabsf(ws.c_re[rb + lane]), fabsf(ws.c_im[rb + lane]));
+        if (lane < n_act) m = fmaxf(fabsf(c_re[lane]), fabsf(c_im[lane]));
         for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
         int e;
         (void)frexpf(m, &e);                                             // m = f * 2^e, f in [0.5, 1)
         const float gs = ldexpf(1.0f, 10 - e);
         if (lane < LPAD) {
             const bool ok = lane < n_act;
-            const double q = ok ? (double)ws.dn[rb + lane] * a.inv_n : 0.0;
+            const double q = ok ? (double)dnp[lane] * a.inv_n : 0.0;
             const double qh = rint(q * 4096.0) * (1.0 / 4096.0);
             L.qtab[lane] = make_float2((float)qh, (float)(q - qh));
-            L.crtab[lane] = ok ? ws.c_re[rb + lane] * gs : 0.f;
-            L.citab[lane] = ok ? ws.c_im[rb + lane] * gs : 0.f;
+            L.crtab[lane] = ok ? c_re[lane] * gs : 0.f;
+            L.citab[lane] = ok ? c_im[lane] * gs : 0.f;
         }
         // A' scale: 64 for unit-modulus array responses; with a codebook the projected responses f are
         // scaled per user so that max |f| lands in [32, 64)
@@ -384,7 +392,7 @@ __device__ __forceinline__ void stage_item(const WsView& ws, const MfmaArgs& a, 
             h2 vh = {(_Float16)0.f, (_Float16)0.f}, vl = vh;
             if (pok && l < n_act) {
                 float s, c;
-                sincos_rev(frac_rev(yr * ws.rx_y[rb + l] + zr * ws.rx_z[rb + l]), s, c);
+                sincos_rev(frac_rev(yr * rx_y[l] + zr * rx_z[l]), s, c);
                 const float2 f = frow[l];
                 split2_f16((c * f.x - s * f.y) * ascale, (c * f.y + s * f.x) * ascale, vh, vl);
             }
@@ -395,7 +403,7 @@ __device__ __forceinline__ void stage_item(const WsView& ws, const MfmaArgs& a, 
         for (int l = l0; l < l0 + LPER; ++l) {
             h2 vh = {(_Float16)0.f, (_Float16)0.f}, vl = vh;
             if (pok && l < n_act) {
-                const double ph = yr * ws.rx_y[rb + l] + zr * ws.rx_z[rb + l] + yt * ws.tx_y[rb + l] + zt * ws.tx_z[rb + l];
+                const double ph = yr * rx_y[l] + zr * rx_z[l] + yt * tx_y[l] + zt * tx_z[l];
                 float s, c;
                 sincos_rev(frac_rev(ph), s, c);
                 split2_f16(c * A_SCALE, s * A_SCALE, vh, vl);
