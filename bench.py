@@ -32,16 +32,25 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense f16/bf16 MFMA ~2.5 PFLOP/s
+CARRIER_HZ = 3.5e9          # carrier of the Doppler term in config 5
 WORKLOADS = {
-    # name: users/GPU, bs_shape, ue_shape, paths, subcarriers
+    # name: users PER GPU (weak scaling: every rank generates this many), bs_shape, ue_shape, paths, subcarriers
     "c3_headline": dict(n_ue=100_000, bs=[8, 8], ue=[2, 2], L=25, N=512),
     "c2_asu_shape": dict(n_ue=10_000, bs=[8, 4], ue=[2, 2], L=10, N=256),
-    "c5_massive": dict(n_ue=6_250, bs=[16, 16], ue=[4, 4], L=25, N=1024),
+    # config 4 = 1M users over 8 GPUs: the per-GPU shard (131 GB of output); `--gpus 8 --workload c4_shard` IS config 4
+    "c4_shard": dict(n_ue=125_000, bs=[8, 8], ue=[2, 2], L=25, N=512),
+    # config 5 = 50k users over 8 GPUs, with the Doppler term: the per-GPU shard (209.7 GB of output)
+    "c5_massive": dict(n_ue=6_250, bs=[16, 16], ue=[4, 4], L=25, N=1024, doppler=True),
+    # DeepMIMO's default arrays (channel.py:36-46: BS 8x1, UE 1x1): the folded matrix-core kernel's regime
+    "d8_default_arrays": dict(n_ue=200_000, bs=[8, 1], ue=[1, 1], L=25, N=512),
+    # headline shape, but the consumer of docs/manual.ipynb cell 105 fused in: 64-beam sweep, no [N, ., K] tensor written
+    "c3_beam_power": dict(n_ue=100_000, bs=[8, 8], ue=[2, 2], L=25, N=512, beams=64),
     "tiny": dict(n_ue=512, bs=[8, 8], ue=[2, 2], L=25, N=512),
 }
 
 
-def synth_device_rays(n_ue, L, seed, device, all_valid=True):
+def synth_device_rays(n_ue, L, seed, device, all_valid=True, doppler=False):
     g = torch.Generator(device=device)
     g.manual_seed(seed)
 
@@ -51,6 +60,9 @@ def synth_device_rays(n_ue, L, seed, device, all_valid=True):
     rays = {"power": U(-140, -60), "phase": U(-180, 180), "delay": U(1e-8, 2e-6),
             "aoa_az": U(-180, 180), "aoa_el": U(0, 180), "aod_az": U(-180, 180), "aod_el": U(0, 180),
             "inter": torch.randint(0, 5, (n_ue, L), generator=g, device=device).to(torch.float32)}
+    if doppler:                                            # vel U(-30, 30) m/s, acc U(-1, 1) m/s^2
+        rays["doppler_vel"] = U(-30, 30)
+        rays["doppler_acc"] = U(-1, 1)
     if not all_valid:
         nvalid = torch.randint(0, L + 1, (n_ue, 1), generator=g, device=device)
         pad = torch.arange(L, device=device)[None, :] >= nvalid
@@ -67,6 +79,7 @@ def make_params(w):
     p.num_paths = w["L"]
     p.ofdm.subcarriers = w["N"]
     p.ofdm.selected_subcarriers = np.arange(w["N"])
+    p.enable_doppler = int(bool(w.get("doppler")))
     p.validate(w["n_ue"])
     return p
 
@@ -75,12 +88,24 @@ def _cpu_chunk(args):
     """One worker's share of the CPU baseline (module-level so multiprocessing can pickle it)."""
     w, n, seed = args
     from oracle import oracle_np as onp
-    rays = onp.synth_rays(n, w["L"], seed=seed, all_valid=True)
+    dop = bool(w.get("doppler"))
+    rays = onp.synth_rays(n, w["L"], seed=seed, all_valid=True, with_doppler=dop)
     op = onp.make_params(bs_antenna=dict(shape=w["bs"]), ue_antenna=dict(shape=w["ue"]), num_paths=w["L"],
-                         ofdm=dict(subcarriers=w["N"], selected_subcarriers=np.arange(w["N"])))
+                         enable_doppler=int(dop), ofdm=dict(subcarriers=w["N"], selected_subcarriers=np.arange(w["N"])))
+    dkw = dict(doppler=dict(vel=rays["doppler_vel"], acc=rays["doppler_acc"], carrier_freq=CARRIER_HZ)) if dop else {}
     t0 = time.perf_counter()
-    onp.compute_channels(rays, op, style="reference")
+    H = onp.compute_channels(rays, op, style="reference", **dkw)["channel"]
+    if w.get("beams"):                                     # the consumer, as docs/manual.ipynb cell 105 writes it
+        F = beam_codebook(w)
+        np.abs(F @ H).mean(axis=1).mean(axis=-1)
     return time.perf_counter() - t0
+
+
+def beam_codebook(w):
+    """The notebook's grid of beams (docs/manual.ipynb cell 105): steering vectors over -60..60 degrees."""
+    import deepmimo_amd as dm
+    return np.array([dm.steering_vec(np.array(w["bs"]), phi=azi).squeeze()
+                     for azi in np.around(np.linspace(-60, 60, w["beams"]), 2)]).reshape(w["beams"], -1)
 
 
 def cpu_baseline_here(w, sample_users, workers):
@@ -102,7 +127,8 @@ def cpu_baseline_here(w, sample_users, workers):
             dtw = time.perf_counter() - t0
         out["all_cores"] = {"value": per * workers / dtw, "unit": "user-channels/s", "cores": workers,
                             "sample": f"{workers} processes x {per} users, {dtw:.1f} s wall"}
-    out["c_port"] = c_port_baseline(w, sample_users, workers)
+    if not w.get("beams"):
+        out["c_port"] = c_port_baseline(w, sample_users, workers)
     return out
 
 
@@ -115,10 +141,14 @@ def c_port_baseline(w, sample_users, workers):
     op = onp.make_params(bs_antenna=dict(shape=w["bs"]), ue_antenna=dict(shape=w["ue"]), num_paths=w["L"],
                          ofdm=dict(subcarriers=w["N"], selected_subcarriers=np.arange(w["N"])))
 
+    dop = bool(w.get("doppler"))
+    op["enable_doppler"] = int(dop)
+
     def run(n, threads, seed):
-        rays = onp.synth_rays(n, w["L"], seed=seed, all_valid=True)
+        rays = onp.synth_rays(n, w["L"], seed=seed, all_valid=True, with_doppler=dop)
+        dkw = dict(doppler=dict(vel=rays["doppler_vel"], acc=rays["doppler_acc"], carrier_freq=CARRIER_HZ)) if dop else {}
         t0 = time.perf_counter()
-        oc.compute_channels(rays, op, threads=threads)
+        oc.compute_channels(rays, op, threads=threads, **dkw)
         return time.perf_counter() - t0
 
     run(max(1, min(16, sample_users // 8)), 1, 98)
@@ -146,19 +176,34 @@ def cpu_baseline(workload, users_override, sample_users, workers):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
+def library_id():
+    """First 12 hex digits of the SHA-256 of the product library this process runs (the built .so travels with the repo
+    snapshot, so the id names one build everywhere)."""
+    import hashlib
+    from deepmimo_amd import _native as nat
+    with open(nat.LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:12]
+
+
 def measured_traffic(workload, n_ue, variant):
     """HBM bytes per stage-2 launch from the committed rocprofv3 PMC passes (profiles/traffic.json:
-    WRITE_SIZE + 2 x FETCH_SIZE in KiB, separate --pmc runs, gfx950 FETCH correction applied).  Only
-    reported when the profiled run matches this run's workload, user count and kernel variant."""
+    WRITE_SIZE + 2 x FETCH_SIZE, separate --pmc runs, gfx950 FETCH correction applied; written by
+    tools/make_traffic_json.py).  Counters cannot be collected inside this process, so the figure comes from the
+    profile - but ONLY when that profile was taken on this very library build (`library_id`), workload, user count and
+    kernel variant; otherwise `traffic` is null and `traffic_note` says why."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
         e = t.get(workload)
-        if e and e["users"] == n_ue and e["variant"] == variant:
-            return e["hbm_bytes_per_launch"]
-    except Exception:
-        pass
-    return None
+        if not e:
+            return None, "no PMC profile committed for this workload"
+        if e["users"] != n_ue or e["variant"] != variant:
+            return None, "committed PMC profile is for another user count / kernel variant"
+        if e.get("library_id") != library_id():
+            return None, f"committed PMC profile ({e.get('profile', '?')}) was taken on library build {e.get('library_id')}, this run is {library_id()}"
+        return e["hbm_bytes_per_launch"], f"rocprofv3 PMC passes {e.get('profile', '?')} on this library build"
+    except Exception as ex:                                    # a missing / malformed profile is not a bench failure
+        return None, f"profiles/traffic.json unreadable: {ex}"
 
 
 def main():
@@ -167,11 +212,13 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3_headline", choices=sorted(WORKLOADS))
-    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 fp32 vector kernel, 2 MFMA kernel")
+    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 fp32 vector kernel, 2 MFMA kernel, 9 small-output, 12 folded")
     ap.add_argument("--users", type=int, default=0, help="override users per GPU")
     ap.add_argument("--cpu-users", type=int, default=-1, help="CPU baseline sample size (0 = skip)")
     ap.add_argument("--random-valid", action="store_true", help="valid paths per user uniform in 0..L")
     ap.add_argument("--cpu-workers", type=int, default=-1, help="processes of the all-cores CPU figure (default min(16, cores))")
+    ap.add_argument("--gather", action="store_true", help="N > 1: also time the side-product all_gather and a bounded channel-slice gather to rank 0")
+    ap.add_argument("--gather-users", type=int, default=2048, help="users per rank in the gathered channel slice")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_workers < 0:
@@ -213,27 +260,44 @@ def main():
     n_ue = w["n_ue"]
     eng = ChannelEngine(dev_index)
     params = make_params(w)
-    rays_t = synth_device_rays(n_ue, w["L"], 1234 + rank, dev, all_valid=not args.random_valid)
+    dop = bool(w.get("doppler"))
+    rays_t = synth_device_rays(n_ue, w["L"], 1234 + rank, dev, all_valid=not args.random_valid, doppler=dop)
     rays = eng.upload_rays(rays_t)
     m_rx, m_tx = w["ue"][0] * w["ue"][1], w["bs"][0] * w["bs"][1]
-    out = torch.empty((n_ue, m_rx, m_tx, w["N"]), dtype=torch.complex64, device=dev)
-
-    # one preparation allocates the workspace once; every step then re-issues BOTH stages on the same buffers
-    # (ChannelEngine.relaunch: two C-ABI calls, no allocation, no host-device copy, no sync)
-    prep0 = eng.prepare(rays, params, want_side=False)
+    n_beams = int(w.get("beams", 0))
     import ctypes as C
     from deepmimo_amd import _native as nat
 
+    # one preparation allocates the workspace once; every step then re-issues BOTH stages on the same buffers
+    # (two C-ABI calls, no allocation, no host-device copy, no sync)
+    prep0 = eng.prepare(rays, params, want_side=False, carrier_freq=CARRIER_HZ if dop else 0.0)
+    p0, wsp = prep0.params_struct, C.c_void_p(prep0.workspace.data_ptr())
+    assert bool(p0.enable_doppler) == dop, "the Doppler term of this workload is not active"
+    if n_beams:
+        # fused consumer (docs/manual.ipynb cell 105): per-beam mean amplitude [n_ue, n_beams]; no channel tensor exists
+        cb = torch.from_numpy(beam_codebook(w)).to(device=dev, dtype=torch.complex64).contiguous()
+        out = torch.empty((n_ue, n_beams), dtype=torch.float32, device=dev)
+        best = torch.empty((n_ue,), dtype=torch.int32, device=dev)
+        bws_bytes = int(eng.lib.dmx_beam_workspace_bytes(C.byref(p0), n_ue, prep0.n_paths_loaded, n_beams))
+        bws = torch.empty(bws_bytes + 256, dtype=torch.uint8, device=dev)
+        bws_ptr = bws.data_ptr() + (-bws.data_ptr()) % 256
+    else:
+        out = torch.empty((n_ue, m_rx, m_tx, w["N"]), dtype=torch.complex64, device=dev)
+
     def step(ev0=None, ev1=None):
-        p, wsp = prep0.params_struct, C.c_void_p(prep0.workspace.data_ptr())
         stream = eng._stream_ptr()
         prep0.side["max_delay_key"].zero_()
-        nat.check(eng.lib.dmx_path_prep(C.byref(prep0.rays_struct), C.byref(p), wsp, prep0.workspace_bytes,
+        nat.check(eng.lib.dmx_path_prep(C.byref(prep0.rays_struct), C.byref(p0), wsp, prep0.workspace_bytes,
                                         C.byref(prep0.side_struct), stream), "dmx_path_prep")
         if ev0 is not None:
             ev0.record(torch.cuda.current_stream(dev))
-        nat.check(eng.lib.dmx_channels_fd(C.byref(p), wsp, prep0.n_ue, prep0.n_paths_loaded, 0, prep0.n_ue,
-                                          C.c_void_p(out.data_ptr()), int(args.variant), stream), "dmx_channels_fd")
+        if n_beams:
+            nat.check(eng.lib.dmx_beam_power(C.byref(p0), wsp, prep0.n_ue, prep0.n_paths_loaded, 0, prep0.n_ue,
+                                             C.c_void_p(cb.data_ptr()), n_beams, C.c_void_p(bws_ptr), bws_bytes,
+                                             C.c_void_p(out.data_ptr()), C.c_void_p(best.data_ptr()), stream), "dmx_beam_power")
+        else:
+            nat.check(eng.lib.dmx_channels_fd(C.byref(p0), wsp, prep0.n_ue, prep0.n_paths_loaded, 0, prep0.n_ue,
+                                              C.c_void_p(out.data_ptr()), int(args.variant), stream), "dmx_channels_fd")
         if ev1 is not None:
             ev1.record(torch.cuda.current_stream(dev))
 
@@ -258,45 +322,118 @@ def main():
         elapsed, k2_ms = float(t[0]), float(t[1])
 
     # a cheap end-to-end sanity check of what was just written (not timed)
-    chk = torch.view_as_real(out[:: max(1, n_ue // 64)])
+    chk = out[:: max(1, n_ue // 64)]
+    chk = torch.view_as_real(chk) if chk.is_complex() else chk
     assert bool(torch.isfinite(chk).all()) and float(chk.abs().max()) > 0, "bench output is not finite / all zero"
 
     total_users = n_ue * world
-    ms_per_step = elapsed / max(args.steps, 1) * 1e3
-    bytes_per_user = 8 * m_rx * m_tx * w["N"] + 4 * w["L"] * 8
-    achieved = n_ue * bytes_per_user / (k2_ms * 1e-3) / 1e9
-    cmacs = n_ue * m_rx * m_tx * w["N"] * w["L"]
+    step_s = elapsed / max(args.steps, 1)
+    choice = int(args.variant) if args.variant else int(eng.lib.dmx_fd_kernel_choice(C.byref(p0), prep0.n_paths_loaded))
+    kernel = "k2c_beam_power" if n_beams else {1: "k2_fd_valu", 2: "k2_fd_mfma", 9: "k2_fd_small", 12: "k2_fd_fold"}.get(choice, "k2_fd_mfma")
+    split = kernel in ("k2_fd_mfma", "k2_fd_fold", "k2c_beam_power")
+    rows = m_rx * (n_beams if n_beams else m_tx)
+    cmacs = n_ue * rows * w["N"] * w["L"]
+    if n_beams:
+        # compute-bound by construction (nothing of size [N, ., K] touches HBM): priced against the dense f16 MFMA peak
+        # with the ALGORITHMIC flops, 8 real flops per complex MAC of the (rx, beam) x path x subcarrier contraction;
+        # the matrix cores execute 3 split terms on 32 padded path slots, i.e. 3 * 32/25 times that
+        flops = 8.0 * cmacs
+        ach = flops / (k2_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / MFMA_F16_PEAK_TFLOPS, "traffic": None,
+                "kernel": "k2c_beam_power (+ k2b_beam_project)", "kernel_ms": k2_ms,
+                "algorithmic_flops_per_launch": flops,
+                "executed_mfma_flops_per_launch": 2.0 * n_ue * ((rows + 31) // 32 * 32) * (2 * w["N"]) * 64 * 3,
+                "output_not_written_bytes": n_ue * 8 * rows * w["N"]}
+    else:
+        bytes_per_user = 8 * m_rx * m_tx * w["N"] + 4 * w["L"] * (10 if dop else 8)
+        achieved = n_ue * bytes_per_user / (k2_ms * 1e-3) / 1e9
+        traffic, note = measured_traffic(args.workload, n_ue, args.variant)
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": note,
+                "kernel": f"stage-2 contraction ({kernel})", "kernel_ms": k2_ms,
+                "algorithmic_bytes_per_launch": n_ue * bytes_per_user}
     res = {
-        "metric": "user-channels/sec", "value": total_users / (elapsed / max(args.steps, 1)),
+        "metric": "user-channels/sec", "value": total_users / step_s,
         "unit": "user-channels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16x3-split MFMA, f32 accumulate" if split else "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {n_ue} users/GPU x BS {w['bs'][0]}x{w['bs'][1]} ({m_tx}) x UE "
                                f"{w['ue'][0]}x{w['ue'][1]} ({m_rx}) antennas x {w['L']} paths "
-                               f"({'random valid count' if args.random_valid else 'all valid'}) x {w['N']} subcarriers",
+                               f"({'random valid count' if args.random_valid else 'all valid'}) x {w['N']} subcarriers"
+                               + (" + Doppler term (f_c 3.5 GHz)" if dop else "")
+                               + (f" -> {n_beams}-beam sweep mean |F @ H| (no channel tensor written)" if n_beams else ""),
                    "users_total": total_users, "parallelism": f"user-shard x{world}",
-                   "fd_kernel_variant": args.variant,
-                   "fd_kernel": {1: "k2_fd_valu", 2: "k2_fd_mfma", 9: "k2_fd_small"}.get(
-                       int(args.variant) if args.variant else
-                       eng.lib.dmx_fd_kernel_choice(C.byref(prep0.params_struct), prep0.n_paths_loaded), "k2_fd_mfma"),
-                   "arithmetic": "fp32 results; k2_fd_mfma contracts on the f16 matrix cores with a 3-term split "
-                                 "(hi*hi + hi*lo + lo*hi, fp32 accumulate, 1.4e-6 of peak measured), the other "
-                                 "stage-2 kernels in fp32; stage 1 in float64",
-                   "complex_macs_per_s": cmacs * world / (elapsed / max(args.steps, 1))},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, n_ue, args.variant),
-                     "kernel": "stage-2 contraction (k2_fd_*)", "kernel_ms": k2_ms,
-                     "algorithmic_bytes_per_launch": n_ue * bytes_per_user},
+                   "fd_kernel_variant": args.variant, "fd_kernel": kernel, "library_id": library_id(),
+                   "arithmetic": "fp32 results; the matrix-core kernels (k2_fd_mfma, k2_fd_fold, k2c_beam_power) contract "
+                                 "f16 hi/lo splits of fp32 operands in 3 terms (hi*hi + hi*lo + lo*hi, fp32 accumulate; "
+                                 "<= 2e-6 of each user's peak measured against the float64 oracle), the other stage-2 "
+                                 "kernels in fp32; stage 1 in float64",
+                   "complex_macs_per_s": cmacs * world / step_s},
+        "roofline": roof,
     }
+    if dist and args.gather:
+        res["gather"] = gather_leg(dist, eng, rays, params, out, n_ue, world, rank, dev, args.gather_users,
+                                   CARRIER_HZ if dop else 0.0)
     if rank == 0 and world == 1:
-        cpu_users = args.cpu_users if args.cpu_users >= 0 else {"c3_headline": 400, "c2_asu_shape": 2000,
-                                                                "c5_massive": 8, "tiny": 100}[args.workload]
+        cpu_users = args.cpu_users if args.cpu_users >= 0 else {"c3_headline": 400, "c2_asu_shape": 2000, "c4_shard": 400,
+                                                                "c5_massive": 8, "d8_default_arrays": 8000,
+                                                                "c3_beam_power": 300, "tiny": 100}[args.workload]
         if cpu_users > 0:
             res["cpu_baseline"] = cpu_baseline(args.workload, 0, cpu_users, args.cpu_workers)
     if rank == 0:
         print(json.dumps(res))
     if dist:
         dist.destroy_process_group()
+
+
+def gather_leg(dist, eng, rays, params, out, n_ue, world, rank, dev, gather_users, carrier):
+    """Bringing results together, timed SEPARATELY from generation: (1) all_gather of the small per-user
+    side products los / num_paths (int32 [N]); (2) point-to-point fan-in of a BOUNDED user slice of the output to
+    rank 0 (the full tensors of configs 3-5 do not fit one GPU).  On RCCL the tensors stay in HBM and each peer's block
+    crosses its one direct xGMI link (~153 GB/s per link is the bound, 7 links ingest at the root concurrently); under
+    the gloo rehearsal (DMX_DIST_BACKEND=gloo, ranks sharing one GPU) they go through host memory."""
+    from deepmimo_amd import dist as ddist
+    on_dev = dist.get_backend() == "nccl"
+    prep = eng.prepare(rays, params, want_side=True, carrier_freq=carrier)
+    los, npaths = prep.side["los"], prep.side["num_paths"]
+    g = max(1, min(n_ue, gather_users))
+    piece = out[:g].contiguous()
+    if not on_dev:
+        los, npaths, piece = los.cpu(), npaths.cpu(), piece.cpu()
+    res = {"backend": dist.get_backend(), "device_tensors": on_dev}
+
+    def timed(fn, reps=3):
+        fn()                                                      # warm-up: communicator setup, first-touch
+        best = float("inf")
+        for _ in range(reps):
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            best = min(best, time.perf_counter() - t0)
+        t = torch.tensor([best], dtype=torch.float64, device=dev if on_dev else torch.device("cpu"))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
+
+    full = {}
+    t_side = timed(lambda: full.update(los=ddist.all_gather_users(los, n_ue * world), num_paths=ddist.all_gather_users(npaths, n_ue * world)))
+    assert full["los"].shape[0] == n_ue * world
+    res["side_products"] = {"what": "all_gather of los + num_paths (int32 [users_total] each)", "ms": t_side * 1e3,
+                            "bytes_total": 2 * 4 * n_ue * world}
+    got = {}
+    t_g = timed(lambda: got.update(x=ddist.gather_users_to_root(piece, g * world, dst=0)))
+    per_peer = piece.numel() * piece.element_size()
+    if rank == 0:
+        assert got["x"].shape[0] == g * world
+    res["channel_slice_to_root"] = {"what": f"point-to-point fan-in of {g} users per rank to rank 0 (batch_isend_irecv)",
+                                    "ms": t_g * 1e3, "bytes_per_peer": per_peer,
+                                    "GBps_per_peer": per_peer / t_g / 1e9,
+                                    "GBps_root_ingest": per_peer * (world - 1) / t_g / 1e9,
+                                    "bound": "one direct xGMI link per peer, ~153 GB/s (MI355X_MICROARCH.md / SURVEY.md 8e)"}
+    return res
 
 
 if __name__ == "__main__":

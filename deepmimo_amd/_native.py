@@ -11,13 +11,13 @@ import os
 # DMX_LIB_PATH lets a measurement load another build of the same ABI (A/B of two libraries); default = in-tree
 LIB_PATH = os.environ.get("DMX_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
                                                           "libdeepmimo_amd.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EXPORTED_SYMBOLS = ("dmx_version", "dmx_last_error", "dmx_workspace_bytes", "dmx_decode_max_delay",
                     "dmx_path_prep", "dmx_channels_fd", "dmx_channels_td", "dmx_channels_fd_lpf",
                     "dmx_lpf_workspace_bytes", "dmx_mat5_find", "dmx_mat_to_rowmajor_f32",
                     "dmx_beam_workspace_bytes", "dmx_channels_fd_beams", "dmx_pathloss",
-                    "dmx_p2m_count_rx", "dmx_p2m_parse_paths", "dmx_fd_kernel_choice")
+                    "dmx_p2m_count_rx", "dmx_p2m_parse_paths", "dmx_fd_kernel_choice", "dmx_beam_power")
 
 PATTERN_IDS = {"isotropic": 0, "halfwave-dipole": 1}
 
@@ -44,7 +44,7 @@ class DmxParams(C.Structure):
                 ("n_subcarriers", C.c_int32), ("n_selected", C.c_int32),
                 ("selected_subcarriers", C.c_void_p),
                 ("bandwidth", C.c_double), ("rx_filter", C.c_int32), ("enable_doppler", C.c_int32),
-                ("carrier_freq", C.c_double)]
+                ("carrier_freq", C.c_double), ("sc_first", C.c_int32), ("sc_stride", C.c_int32)]
 
 
 class DmxSide(C.Structure):
@@ -106,6 +106,9 @@ def load():
     lib.dmx_channels_fd_beams.restype = C.c_int
     lib.dmx_channels_fd_beams.argtypes = [C.POINTER(DmxParams), C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64,
                                           C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.dmx_beam_power.restype = C.c_int
+    lib.dmx_beam_power.argtypes = [C.POINTER(DmxParams), C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64,
+                                   C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.dmx_p2m_count_rx.restype = C.c_int64
     lib.dmx_p2m_count_rx.argtypes = [C.c_void_p, C.c_size_t]
     lib.dmx_p2m_parse_paths.restype = C.c_int

@@ -6,7 +6,9 @@ The reference declares ``use_gpu`` / ``gpu_device_id`` (config.py:58-59) but not
 here they select the device the MI355X kernels run on.  This package has no CPU channel path:
 ``use_gpu`` defaults to True and switching it off makes ``compute_channels`` raise.
 Extra key: ``channel_output`` = 'numpy' (reference-compatible return type) or 'torch' (keep the
-complex64 tensor resident in HBM - required when it does not fit host memory)."""
+complex64 tensor resident in HBM - required when it does not fit host memory); ``strict_reference_cache``
+reproduces the reference's cache staleness when only a radiation pattern changes (Dataset._params_for_prep);
+``host_copy_guard`` makes ``compute_channels`` raise instead of copying a tensor larger than the free host memory."""
 from __future__ import annotations
 
 from typing import Any
@@ -18,7 +20,9 @@ class _Config:
         "gpu_device_id": 0,
         "scenarios_folder": "deepmimo_scenarios",
         "channel_output": "numpy",
-        "fd_kernel_variant": 0,      # 0 auto, 1 fp32 vector kernel, 2 split-precision MFMA kernel, 9 small-output kernel
+        "fd_kernel_variant": 0,      # 0 auto, 1 fp32 vector kernel, 2 split-precision MFMA kernel, 9 small-output kernel, 12 folded
+        "strict_reference_cache": False,   # True: keep the reference's stale `_power_linear_ant_gain` (dataset.py:213-220)
+        "host_copy_guard": True,     # refuse a NumPy copy of the channel tensor that exceeds the free host memory
     }
 
     def __init__(self):

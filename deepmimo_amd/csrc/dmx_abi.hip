@@ -16,6 +16,15 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+int device_cu_count() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+        (void)hipGetLastError();
+        cus = 256;                                        // MI355X
+    }
+    return cus;
+}
+
 static int check_params(const dmx_params* p) {
     if (!p) { set_error("params is NULL"); return DMX_ERR_ARG; }
     for (int i = 0; i < 2; ++i) {
@@ -34,6 +43,7 @@ static int check_params(const dmx_params* p) {
             set_error("selected_subcarriers missing"); return DMX_ERR_ARG;
         }
         if (!(p->bandwidth > 0)) { set_error("ofdm.bandwidth must be > 0"); return DMX_ERR_ARG; }
+        if (p->sc_stride < 0) { set_error("sc_stride must be >= 0"); return DMX_ERR_ARG; }
     }
     return DMX_OK;
 }
@@ -109,7 +119,7 @@ int dmx_channels_fd(const dmx_params* prm, const void* workspace, int64_t n_ue, 
     if (rc) return rc;
     if (!prm->freq_domain) { set_error("dmx_channels_fd called with freq_domain = 0"); return DMX_ERR_ARG; }
     if (prm->rx_filter) { set_error("rx_filter = 1 is handled by dmx_channels_fd_lpf"); return DMX_ERR_ARG; }
-    if (variant < 0 || variant > 11) { set_error("unknown variant %d", variant); return DMX_ERR_ARG; }
+    if (variant < 0 || variant > 12) { set_error("unknown variant %d", variant); return DMX_ERR_ARG; }
     if (prm->n_selected == 0) return DMX_OK;
     return launch_channels_fd(*prm, ws, user_begin, user_count, (float2*)out_c64, variant, (hipStream_t)stream);
 }
@@ -166,6 +176,26 @@ int dmx_channels_fd_beams(const dmx_params* prm, const void* workspace, int64_t 
     }
     return launch_channels_fd_beams(*prm, ws, user_begin, user_count, (const float2*)codebook_c64, n_beams, beam_workspace,
                                     (float2*)out_c64, (hipStream_t)stream);
+}
+
+int dmx_beam_power(const dmx_params* prm, const void* workspace, int64_t n_ue, int32_t n_paths_loaded,
+                   int64_t user_begin, int64_t user_count, const void* codebook_c64, int32_t n_beams,
+                   void* beam_workspace, size_t beam_workspace_bytes_, float* out_mean_amp, int32_t* out_best_beam,
+                   void* stream) {
+    WsView ws;
+    int rc = stage2_common(prm, workspace, n_ue, n_paths_loaded, user_begin, user_count, out_mean_amp, &ws);
+    if (rc) return rc;
+    if (!prm->freq_domain || prm->rx_filter) { set_error("dmx_beam_power needs freq_domain = 1 and rx_filter = 0"); return DMX_ERR_ARG; }
+    if (n_beams < 1 || !codebook_c64) { set_error("codebook missing"); return DMX_ERR_ARG; }
+    if (prm->n_selected < 1) { set_error("dmx_beam_power needs at least one selected subcarrier"); return DMX_ERR_ARG; }
+    if (ws.P > 32) { set_error("num_paths = %d exceeds the 32 paths the beam-space kernels support", ws.P); return DMX_ERR_SHAPE; }
+    const size_t need = beam_workspace_bytes(user_count, n_beams, ws.P);
+    if (!beam_workspace || beam_workspace_bytes_ < need || ((uintptr_t)beam_workspace & 255u)) {
+        set_error("beam workspace too small or misaligned: need %zu bytes, 256-byte aligned", need);
+        return DMX_ERR_WORKSPACE;
+    }
+    return launch_beam_power(*prm, ws, user_begin, user_count, (const float2*)codebook_c64, n_beams, beam_workspace,
+                             out_mean_amp, out_best_beam, (hipStream_t)stream);
 }
 
 int dmx_channels_td(const dmx_params* prm, const void* workspace, int64_t n_ue, int32_t n_paths_loaded,

@@ -68,6 +68,9 @@ __device__ __forceinline__ float frac_rev(double t) {
 
 void set_error(const char* fmt, ...);
 
+// compute units of the current device (persistent grids are sized from it)
+int device_cu_count();
+
 // stage launchers (defined next to their kernels)
 int launch_path_prep(const dmx_rays& rays, const dmx_params& prm, const WsView& ws, const dmx_side& side,
                      hipStream_t stream);
@@ -79,6 +82,8 @@ int launch_channels_fd_lpf(const dmx_params& prm, const WsView& ws, int64_t user
 int launch_channels_fd_beams(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
                              const float2* codebook, int n_beams, void* beam_ws, float2* out, hipStream_t stream);
 size_t beam_workspace_bytes(int64_t user_count, int n_beams, int P);
+int launch_beam_power(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
+                      const float2* codebook, int n_beams, void* beam_ws, float* out_amp, int32_t* out_best, hipStream_t stream);
 bool fd_mfma_supported(const dmx_params& prm, const WsView& ws);
 int launch_channels_td(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
                        float2* out, hipStream_t stream);

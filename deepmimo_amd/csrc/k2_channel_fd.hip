@@ -282,10 +282,15 @@ bool fd_mfma_preferred(const dmx_params& prm, const WsView& ws);
 int launch_channels_fd_small(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
                              float2* out, hipStream_t stream);
 bool fd_small_preferred(const dmx_params& prm, const WsView& ws);
+int launch_channels_fd_fold(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count, float2* out,
+                            int chunk_blocks, hipStream_t stream);
+bool fd_fold_preferred(const dmx_params& prm, const WsView& ws);
 
-// what variant 0 runs for this shape: 9 small-output kernel, 2 matrix cores, 1 fp32 vector kernel
+// what variant 0 runs for this shape: 9 small-output kernel, 12 folded matrix-core kernel (few antenna pairs, uniformly
+// spaced subcarriers), 2 matrix cores, 1 fp32 vector kernel
 int fd_auto_choice(const dmx_params& prm, const WsView& ws) {
     if (fd_small_preferred(prm, ws)) return 9;
+    if (fd_fold_preferred(prm, ws)) return 12;
     if (fd_mfma_preferred(prm, ws)) return 2;
     return 1;
 }
@@ -293,7 +298,7 @@ int fd_auto_choice(const dmx_params& prm, const WsView& ws) {
 int launch_channels_fd(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
                        float2* out, int variant, hipStream_t stream) {
     if (user_count == 0) return DMX_OK;
-    if (variant >= 2 && variant != 9 && !fd_mfma_supported(prm, ws)) {
+    if (variant >= 2 && variant != 9 && variant != 12 && !fd_mfma_supported(prm, ws)) {
         set_error("MFMA variant does not support this shape");
         return DMX_ERR_SHAPE;
     }
@@ -301,6 +306,8 @@ int launch_channels_fd(const dmx_params& prm, const WsView& ws, int64_t user_beg
     if (variant == 0) variant = fd_auto_choice(prm, ws);
     if (variant == 9)
         rc = launch_channels_fd_small(prm, ws, user_begin, user_count, out, stream);
+    else if (variant == 12)
+        rc = launch_channels_fd_fold(prm, ws, user_begin, user_count, out, 0, stream);
     else if (variant >= 2)
         rc = launch_channels_fd_mfma(prm, ws, user_begin, user_count, out, variant >= 3 ? variant - 2 : 0, stream);
     else

@@ -1,0 +1,322 @@
+// Stage 2, frequency domain - "folded" matrix-core kernel for FEW antenna pairs (variant 12; the automatic choice for
+// DeepMIMO's default-sized arrays - channel.py:36-46: BS 8x1, UE 1x1 - up to 32 pairs when the selected subcarriers
+// are uniformly spaced).
+//
+// The plain matrix-core kernel (k2_channel_fd_mfma.hip) generates the subcarrier phasors G[l,k] = c_l e^{-j 2pi q_l sc_k}
+// (q_l = dn_l / N) once per 16-subcarrier strip and reuses them over the M/32 row tiles of a user: with M <= 32 antenna
+// pairs there is ONE half-empty tile per strip, the L x K sin/cos + f16 splits of G are the whole kernel (9-25 % of HBM).
+// For a uniformly spaced selection sc_k = sc_0 + d*k the phasor factorises over k = 16a + b:
+//     G[l, 16a+b] = c_l e^{-j 2pi q_l (sc_0 + 16 d a)} * e^{-j 2pi q_l d b} = c_l E1[l,a] * E2[l,b]
+// so  H[p, 16a+b] = sum_l (A[p,l] c_l E1[l,a]) * E2[l,b]:
+// the 16-subcarrier blocks `a` FOLD INTO THE ROW dimension.  Per user the product is a real GEMM
+//     C[(a,p)][2b+c] = sum_kk At'[(a,p)][kk] * E2'[kk][2b+c]        kk = 2l + {re, im}, 64 deep (32 path slots)
+// with ONE 32-column B operand E2' (16 sin/cos pairs per lane per user, kept in registers) and M*K/16 rows that are
+// packed densely into 32-row tiles whatever M is (8 pairs: four subcarrier blocks per tile).  The A operand
+// At[(a,p)][l] = Ac[p][l] * E1[a][l] is one complex multiply of two small per-user tables (Ac = c_l a_rx a_tx: M x 32,
+// E1: K/16 x 32 entries) - the sin/cos count per user drops from L*K to L*(16 + K/16 + M).
+// Precision: as in k2_channel_fd_mfma.hip - operands split x = hi + lo in f16, three MFMAs (hi*hi + hi*lo + lo*hi)
+// into one fp32 accumulator, power-of-two operand scales undone exactly in the epilogue; the two extra fp32 complex
+// products per operand add ~2e-7 relative.
+//
+// Mapping: ONE WAVE owns one (user, chunk of <= CH subcarrier blocks) work item from start to end - no workgroup
+// barrier after the start-up tables, nothing shared between the four waves of a workgroup but the user-independent
+// row tables.  Per item: path records -> per-wave LDS tables (Ac, E1, q) -> E2' fragments in registers -> per 32-row
+// tile: At' fragments built in registers straight into the MFMA operand layout (4 complex products + 4 packed f16
+// splits per K-step), 3 MFMAs per K-step, 16 non-temporal buffer_store_dword (two 128-B row segments each; the row
+// offsets come from a table because row (a,p) lives at (p*K + 16a)*8 bytes).  Persistent grid.
+#include "dmx_common.h"
+#include <stdlib.h>
+
+namespace dmx {
+
+typedef _Float16 fh8 __attribute__((ext_vector_type(8)));
+typedef _Float16 fh2 __attribute__((ext_vector_type(2)));
+typedef __fp16 fhp2 __attribute__((ext_vector_type(2)));
+typedef float ff16 __attribute__((ext_vector_type(16)));
+
+static constexpr int FOLD_TROW = 272;            // bytes per table row: 32 complex64 + 16 B pad (conflict-free ds_read_b128)
+static constexpr float FOLD_B_SCALE = 64.0f;     // 2^6 on the unit-modulus E2' operand
+static constexpr int FOLD_MAX_M = 64;
+
+struct FoldArgs {
+    int64_t user_begin;
+    int m_tx, ue_mh, bs_mh;
+    int M, K;
+    int sc_first, sc_stride;
+    double inv_n;
+    int ch;            // subcarrier blocks per work item (chunk)
+    int nblk;          // ceil(K / 16)
+    int nchunk;        // ceil(nblk / ch)
+    int nb_last;       // blocks of the last chunk
+    int tab_rows;      // rows of the row tables (multiple of 32)
+    int k_tail;        // K - 16*(nblk-1): valid subcarriers of the last block (1..16)
+};
+
+__device__ __forceinline__ void fold_split2(float x0, float x1, fh2& hi, fh2& lo) {
+    const fhp2 h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+    const fhp2 l = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
+    hi = __builtin_bit_cast(fh2, h);
+    lo = __builtin_bit_cast(fh2, l);
+}
+
+// a wave's own LDS writes are visible to its later reads (DS operations of one wave execute in order); the compiler
+// only has to be kept from moving accesses across this point
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__host__ __device__ inline size_t fold_static_bytes(int tab_rows, int M) { return (size_t)tab_rows * 12 + align_up((size_t)M * 4, 16); }
+__host__ __device__ inline size_t fold_wave_bytes(int M, int ch) { return 256 + (size_t)(M + ch) * FOLD_TROW; }
+
+template <bool NT>
+__global__ __launch_bounds__(256, 4) void k2_fd_fold(WsView ws, FoldArgs a, float* __restrict__ out, int64_t items) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* rowoff0 = reinterpret_cast<uint32_t*>(smem);                 // [tab_rows] byte offset of row (a,p), full chunk
+    uint32_t* rowoff1 = rowoff0 + a.tab_rows;                              // [tab_rows] same for the last chunk
+    uint32_t* rowsrc = rowoff1 + a.tab_rows;                               // [tab_rows] (E1 row | Ac row << 16) byte offsets
+    uint32_t* pidx = rowsrc + a.tab_rows;                                  // [M] element indices of pair p, 4 x u8
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned char* wbase = smem + fold_static_bytes(a.tab_rows, a.M) + (size_t)wave * fold_wave_bytes(a.M, a.ch);
+    float2* qtab = reinterpret_cast<float2*>(wbase);                       // [32] q_l as (multiple of 2^-12, remainder)
+    unsigned char* Ac = wbase + 256;                                       // [M][FOLD_TROW]  c_l a_rx a_tx (scaled)
+    unsigned char* E1 = Ac + (size_t)a.M * FOLD_TROW;                      // [ch][FOLD_TROW] e^{-j 2pi q_l sc(16 a)}
+
+    // ---- user-independent tables, once per workgroup
+    const int M = a.M, K = a.K;
+    for (int r = tid; r < a.tab_rows; r += 256) {
+        const int ab = r / M, p = r - ab * M;
+        const uint32_t off = (uint32_t)(p * K + 16 * ab) * 8u;
+        const int nb0 = a.nchunk > 1 ? a.ch : a.nb_last;
+        // rows past the item: 0xC0000000 stays beyond num_records (< 2^30) under either lane mask and cannot wrap
+        // when the lane's column offset is added
+        rowoff0[r] = ab < nb0 ? off : 0xC0000000u;
+        uint32_t o1 = ab < a.nb_last ? off : 0xC0000000u;
+        if (ab == a.nb_last - 1 && a.k_tail < 16) o1 |= 0x80000000u;      // partial last block: lanes past K keep bit 31
+        rowoff1[r] = o1;
+        const bool any = ab < (a.ch > a.nb_last ? a.ch : a.nb_last);
+        rowsrc[r] = any ? ((uint32_t)(ab * FOLD_TROW) | ((uint32_t)(p * FOLD_TROW) << 16)) : 0u;
+    }
+    for (int p = tid; p < M; p += 256) {
+        const int rx = p / a.m_tx, tx = p - rx * a.m_tx;
+        pidx[p] = (uint32_t)(rx % a.ue_mh) | ((uint32_t)(rx / a.ue_mh) << 8) | ((uint32_t)(tx % a.bs_mh) << 16) |
+                  ((uint32_t)(tx / a.bs_mh) << 24);
+    }
+    __syncthreads();
+
+    const int lp = lane & 31, hh = lane >> 5;
+    const int col = lane & 31, bsc = col >> 1, cpart = col & 1;
+    const int kb = a.sc_stride * bsc;
+    const float kbl = (float)(kb & 4095), kbf = (float)kb, cq = 0.25f * (float)cpart;
+    const uint32_t lane_col = (uint32_t)col * 4u;
+    const uint32_t lmask_last = bsc < a.k_tail ? 0x7FFFFFFFu : 0xFFFFFFFFu;
+    const size_t user_floats = (size_t)M * K * 2;
+
+    for (int64_t item = (int64_t)blockIdx.x * 4 + wave; item < items; item += (int64_t)gridDim.x * 4) {
+        const int64_t ul = item / a.nchunk;
+        const int chunk = (int)(item - ul * a.nchunk);
+        const int64_t u = a.user_begin + ul;
+        const bool last = chunk == a.nchunk - 1;
+        const int nb = last ? a.nb_last : a.ch;                            // subcarrier blocks of this item
+        const int a0 = chunk * a.ch;
+        float* __restrict__ o = out + (size_t)ul * user_floats + (size_t)a0 * 32;
+        int n_act = ws.n_keep[u];
+        n_act = n_act < 32 ? n_act : 32;
+        if (n_act == 0) {                                                  // channel.py:270-271
+            const int k0 = a0 * 16, k1 = (k0 + nb * 16) < K ? (k0 + nb * 16) : K;
+            const int nfl = (k1 - k0) * 2;
+            for (int p = 0; p < M; ++p)
+                for (int i = lane; i < nfl; i += 64) o[(size_t)p * K * 2 + i] = 0.f;
+            continue;
+        }
+        // ---- path records of this user: lane (and lane + 32) = path slot
+        const size_t rb = (size_t)u * ws.P + lp;
+        const bool ok = lp < n_act;
+        const float cr = ok ? ws.c_re[rb] : 0.f, ci = ok ? ws.c_im[rb] : 0.f;
+        const double q = ok ? (double)ws.dn[rb] * a.inv_n : 0.0;
+        const double rxy = ok ? ws.rx_y[rb] : 0.0, rxz = ok ? ws.rx_z[rb] : 0.0;
+        const double txy = ok ? ws.tx_y[rb] : 0.0, txz = ok ? ws.tx_z[rb] : 0.0;
+        float m = fmaxf(fabsf(cr), fabsf(ci));
+        for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        int e;
+        (void)frexpf(m, &e);                                               // m = f * 2^e, f in [0.5, 1)
+        const float gs = ldexpf(1.0f, 10 - e);                             // max |c| component -> [512, 1024)
+        const float oscale = ldexpf(1.0f, e - 10 - 6);                     // 1 / (gs * FOLD_B_SCALE)
+        const double qh = rint(q * 4096.0) * (1.0 / 4096.0);
+        const float qhf = (float)qh, qlf = (float)(q - qh);
+        const float cgr = cr * gs, cgi = ci * gs;
+        wave_lds_sync();                                                   // the previous item's table reads are done
+        if (lane < 32) qtab[lane] = make_float2(qhf, qlf);
+        // Ac[p][l] = c_l a_rx[rx,l] a_tx[tx,l]   (geometry.py:85-102; phases in float64 revolutions)
+        for (int p = hh; p < M; p += 2) {
+            const uint32_t ix = pidx[p];
+            const double ph = (double)(ix & 255u) * rxy + (double)((ix >> 8) & 255u) * rxz +
+                              (double)((ix >> 16) & 255u) * txy + (double)(ix >> 24) * txz;
+            float s, c;
+            sincos_rev(frac_rev(ph), s, c);
+            *reinterpret_cast<float2*>(Ac + (size_t)p * FOLD_TROW + lp * 8) = make_float2(cgr * c - cgi * s, cgr * s + cgi * c);
+        }
+        // E1[a][l] = e^{-j 2pi q_l sc(16 (a0 + a))}; q = qh + ql with qh a multiple of 2^-12, so qh * (sc mod 4096) is
+        // exact in float32 and qh * (sc - sc mod 4096) is an integer (k2_channel_fd_mfma.hip gen_b_step)
+        for (int ab = hh; ab < nb; ab += 2) {
+            const int sca = a.sc_first + a.sc_stride * 16 * (a0 + ab);
+            const float p1 = qhf * (float)(sca & 4095);
+            float s, c;
+            sincos_rev(fmaf(qlf, (float)sca, p1 - rintf(p1)), s, c);
+            *reinterpret_cast<float2*>(E1 + (size_t)ab * FOLD_TROW + lp * 8) = make_float2(c, -s);
+        }
+        wave_lds_sync();
+
+        // ---- E2' fragments (B operand, 32 columns = 16 subcarrier offsets x {re, im}); element j of K-step s is row
+        // kk = 16s + 8h + j, i.e. path 8s + 4h + (j>>1), component j&1.  Column c = 0 holds (Re G, -Im G) = (cos, sin)
+        // of the phase, column c = 1 holds (Im G, Re G) = the same pair a quarter revolution later.
+        const int nsteps = (n_act + 7) >> 3;
+        fh8 Bhi[4], Blo[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            Bhi[s] = fh8{0, 0, 0, 0, 0, 0, 0, 0};
+            Blo[s] = Bhi[s];
+            if (s < nsteps) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float2 qq = qtab[8 * s + 4 * hh + jj];
+                    const float p1 = fmaf(qq.x, kbl, cq);
+                    float sn, cs;
+                    sincos_rev(fmaf(qq.y, kbf, p1 - rintf(p1)), sn, cs);
+                    fh2 ph, pl;
+                    fold_split2(cs * FOLD_B_SCALE, sn * FOLD_B_SCALE, ph, pl);
+                    Bhi[s][2 * jj] = ph[0]; Bhi[s][2 * jj + 1] = ph[1];
+                    Blo[s][2 * jj] = pl[0]; Blo[s][2 * jj + 1] = pl[1];
+                }
+            }
+        }
+
+        // ---- row tiles: 32 rows (a,p) each
+        const uint32_t* rowoff = last ? rowoff1 : rowoff0;
+        const uint32_t lmask = last ? lmask_last : 0x7FFFFFFFu;
+        const int rows = nb * M;
+        const int ntiles = (rows + 31) >> 5;
+        const __amdgpu_buffer_rsrc_t orsrc =
+            __builtin_amdgcn_make_buffer_rsrc(o, 0, (int)((unsigned)(user_floats - (size_t)a0 * 32) * 4u), 0x00020000);
+        for (int rt = 0; rt < ntiles; ++rt) {
+            const uint32_t src = rowsrc[(rt << 5) + lp];
+            const unsigned char* arow = Ac + (src >> 16) + hh * 32;
+            const unsigned char* erow = E1 + (src & 0xFFFFu) + hh * 32;
+            ff16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (s < nsteps) {
+                    const float4 x0 = *reinterpret_cast<const float4*>(arow + s * 64);
+                    const float4 x1 = *reinterpret_cast<const float4*>(arow + s * 64 + 16);
+                    const float4 y0 = *reinterpret_cast<const float4*>(erow + s * 64);
+                    const float4 y1 = *reinterpret_cast<const float4*>(erow + s * 64 + 16);
+                    fh8 Ah, Al;
+                    fh2 ph, pl;
+                    fold_split2(x0.x * y0.x - x0.y * y0.y, x0.x * y0.y + x0.y * y0.x, ph, pl);
+                    Ah[0] = ph[0]; Ah[1] = ph[1]; Al[0] = pl[0]; Al[1] = pl[1];
+                    fold_split2(x0.z * y0.z - x0.w * y0.w, x0.z * y0.w + x0.w * y0.z, ph, pl);
+                    Ah[2] = ph[0]; Ah[3] = ph[1]; Al[2] = pl[0]; Al[3] = pl[1];
+                    fold_split2(x1.x * y1.x - x1.y * y1.y, x1.x * y1.y + x1.y * y1.x, ph, pl);
+                    Ah[4] = ph[0]; Ah[5] = ph[1]; Al[4] = pl[0]; Al[5] = pl[1];
+                    fold_split2(x1.z * y1.z - x1.w * y1.w, x1.z * y1.w + x1.w * y1.z, ph, pl);
+                    Ah[6] = ph[0]; Ah[7] = ph[1]; Al[6] = pl[0]; Al[7] = pl[1];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bhi[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Blo[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bhi[s], acc, 0, 0, 0);
+                }
+            }
+            // accumulator register i is row (i&3) + 8*(i>>2) + 4*(lane>>5) of the tile, column lane&31
+            const uint4* ro4 = reinterpret_cast<const uint4*>(rowoff + (rt << 5) + 4 * hh);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint4 ro = ro4[2 * g];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * g + 0] * oscale), orsrc, lane_col + (ro.x & lmask), 0, NT ? 2 : 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * g + 1] * oscale), orsrc, lane_col + (ro.y & lmask), 0, NT ? 2 : 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * g + 2] * oscale), orsrc, lane_col + (ro.z & lmask), 0, NT ? 2 : 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * g + 3] * oscale), orsrc, lane_col + (ro.w & lmask), 0, NT ? 2 : 0);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+bool fd_fold_supported(const dmx_params& prm, const WsView& ws) {
+    (void)ws;
+    const int64_t M = (int64_t)prm.ue_shape[0] * prm.ue_shape[1] * prm.bs_shape[0] * prm.bs_shape[1];
+    return prm.sc_stride > 0 && prm.n_selected >= 1 && M <= FOLD_MAX_M;
+}
+
+// blocks per work item: the largest of 32 / 16 / 8 that lets at least three workgroups share a CU's 160 KiB of LDS
+static int fold_chunk_blocks(int M, int nblk, int forced) {
+    int best = 8;
+    const int cand[3] = {32, 16, 8};
+    for (int ch : cand) {
+        if (forced > 0 && ch != forced) continue;
+        const int c = ch < nblk ? ch : nblk;
+        const int tab = (M * c + 31) / 32 * 32;
+        const size_t smem = fold_static_bytes(tab, M) + 4 * fold_wave_bytes(M, c);
+        if (forced > 0 || smem * 3 <= 160 * 1024) { best = ch; break; }
+    }
+    return best < nblk ? best : nblk;
+}
+
+// Automatic choice (variant 0): up to 32 pairs from 32 subcarriers on.  TODO(sweep): crossovers from tools/fold_sweep.sh
+bool fd_fold_preferred(const dmx_params& prm, const WsView& ws) {
+    const int64_t M = (int64_t)prm.ue_shape[0] * prm.ue_shape[1] * prm.bs_shape[0] * prm.bs_shape[1];
+    return fd_fold_supported(prm, ws) && M <= 32 && prm.n_selected >= 32;
+}
+
+int launch_channels_fd_fold(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count, float2* out,
+                            int chunk_blocks, hipStream_t stream) {
+    if (user_count == 0 || prm.n_selected == 0) return DMX_OK;
+    if (!fd_fold_supported(prm, ws)) {
+        set_error("the folded kernel needs a uniformly spaced subcarrier selection (dmx_params.sc_stride > 0) and at most %d antenna pairs", FOLD_MAX_M);
+        return DMX_ERR_SHAPE;
+    }
+    FoldArgs a;
+    a.user_begin = user_begin;
+    a.m_tx = prm.bs_shape[0] * prm.bs_shape[1];
+    a.ue_mh = prm.ue_shape[0];
+    a.bs_mh = prm.bs_shape[0];
+    a.M = prm.ue_shape[0] * prm.ue_shape[1] * a.m_tx;
+    a.K = prm.n_selected;
+    a.sc_first = prm.sc_first;
+    a.sc_stride = prm.sc_stride;
+    a.inv_n = 1.0 / (double)prm.n_subcarriers;
+    a.nblk = (a.K + 15) / 16;
+    if (chunk_blocks <= 0) {                       // measurement hook: DMX_FOLD_CHUNK=8|16|32 overrides the LDS-occupancy rule
+        const char* env = getenv("DMX_FOLD_CHUNK");
+        if (env) chunk_blocks = atoi(env);
+        if (chunk_blocks != 8 && chunk_blocks != 16 && chunk_blocks != 32) chunk_blocks = 0;
+    }
+    a.ch = fold_chunk_blocks(a.M, a.nblk, chunk_blocks);
+    a.nchunk = (a.nblk + a.ch - 1) / a.ch;
+    a.nb_last = a.nblk - a.ch * (a.nchunk - 1);
+    a.tab_rows = (a.M * a.ch + 31) / 32 * 32;
+    a.k_tail = a.K - 16 * (a.nblk - 1);
+    if ((size_t)a.M * (size_t)a.K * 8 >= (size_t)1 << 30) { set_error("%d x %d outputs per user are too many for the folded kernel", a.M, a.K); return DMX_ERR_SHAPE; }
+    const size_t smem = fold_static_bytes(a.tab_rows, a.M) + 4 * fold_wave_bytes(a.M, a.ch);
+    if (smem > 160 * 1024) { set_error("folded kernel tables of %zu bytes exceed LDS", smem); return DMX_ERR_SHAPE; }
+    const int64_t items = user_count * a.nchunk;
+    const void* kfn = reinterpret_cast<const void*>(k2_fd_fold<true>);
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, smem) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 1;
+    }
+    int64_t grid = (int64_t)device_cu_count() * per_cu;
+    const int64_t need = (items + 3) / 4;
+    if (grid > need) grid = need;
+    hipLaunchKernelGGL((k2_fd_fold<true>), dim3((unsigned)grid), dim3(256), smem, stream, ws, a, reinterpret_cast<float*>(out), items);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("k2_fd_fold launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
+    return DMX_OK;
+}
+
+}  // namespace dmx

@@ -28,19 +28,9 @@
 //            contiguous 128-B row segments of the output - no LDS transpose, no shuffles; the row is
 //            a scalar offset of the buffer instruction, so the epilogue is 1 VALU op per store.
 // HBM traffic = the 8*M*K output bytes (written once) + ~1 KB of path records per user.
-#include "dmx_common.h"
+#include "k2_mfma_frag.h"
 
 namespace dmx {
-
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-typedef float f16v __attribute__((ext_vector_type(16)));
-
-static constexpr int ROW_BYTES = 144;        // 64 f16 + 16 B pad
-static constexpr int MAX_ROWS = 256;         // antenna pairs per workgroup
-static constexpr int MFMA_LDS_MAX = 80 * 1024;   // two workgroups per CU
-static constexpr int LPAD = 32;              // path slots (kk = 64)
-static constexpr float A_SCALE = 64.0f;      // 2^6
 
 struct MfmaArgs {
     int64_t user_begin;
@@ -58,86 +48,6 @@ struct MfmaArgs {
     // rx_filter variant: per-path subcarrier gains precomputed by k3_lpf_* instead of generated here
     const float2* gtab;      // [user_count, P, K] or nullptr
 };
-
-// (x0, x1) -> packed hi pair and packed lo pair, x = hi + lo.  v_cvt_pkrtz_f16_f32 converts two floats per
-// instruction; with round-toward-zero x - hi is exact in fp32 and lo keeps 11 more bits of it.
-typedef __fp16 hp2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split2_f16(float x0, float x1, h2& hi, h2& lo) {
-    const hp2 h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-    const hp2 l = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
-    hi = __builtin_bit_cast(h2, h);
-    lo = __builtin_bit_cast(h2, l);
-}
-
-// B' fragments of one lane for strip `strip` (32 columns = 16 subcarriers, re/im interleaved): element j of
-// K-step s is row kk = 16s + 8h + j of B', i.e. path l = 8s + 4h + (j>>1), component j&1.
-struct BLane {                      // what a lane knows about its column of the strip
-    int kidx, c;                    // subcarrier index in the selection, re/im column
-    bool kok;                       // column inside the selection
-    unsigned lane_off;              // byte offset of (row 4h, this column) inside a 32-row tile of the output
-    float kl, kf;                   // selected subcarrier number: its low 12 bits (exact) and the whole (both as float)
-};
-
-__device__ __forceinline__ BLane b_lane(int strip, int col, int hh, size_t twoK, const int32_t* __restrict__ sc) {
-    BLane b;
-    const int ncol = (strip << 5) + col;                                // column of C = 2*kidx + c
-    b.kidx = ncol >> 1; b.c = ncol & 1;
-    b.kok = (size_t)ncol < twoK;
-    b.lane_off = ((unsigned)(4 * hh) * (unsigned)twoK + (unsigned)ncol) * 4u;
-    const int kki = b.kok ? sc[b.kidx] : 0;
-    b.kl = (float)(kki & 4095);
-    b.kf = (float)kki;
-    return b;
-}
-
-// one K-step (8 paths) of the strip's B' fragments
-__device__ __forceinline__ void gen_b_step(int s, const BLane& bl, int hh, int n_act, const float2* qtab, const float* crtab,
-                                           const float* citab, const float2* __restrict__ grow, int K, float gs,
-                                           h8& Bhi, h8& Blo) {
-    Bhi = h8{0, 0, 0, 0, 0, 0, 0, 0};
-    Blo = Bhi;
-    if (8 * s >= n_act) return;
-    const int c = bl.c;
-    // this lane evaluates paths jj = 2c, 2c+1 of the step, its pair lane (same subcarrier, other re/im column)
-    // the other two; swap through a lane-pair shuffle
-    float mr[2], mi[2], orr[2], oi[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int pl = 8 * s + 4 * hh + 2 * c + t;
-        if (grow) {                                                     // rx_filter: G[l,k] from the k3 table
-            float2 g = make_float2(0.f, 0.f);
-            if (bl.kok && pl < n_act) g = grow[(size_t)pl * K + bl.kidx];
-            mr[t] = g.x * gs; mi[t] = g.y * gs;
-        } else {
-            float sn, cs;
-            // Phase dn_l sc_k / N in revolutions without float64: q = dn/N is held as qh + ql with qh a multiple of
-            // 2^-12 in [0, 1], so qh * (k mod 4096) is exact in float32 and qh * (k - k mod 4096) is an integer
-            // (drops out); ql <= 2^-13 carries the rest (its product is rounded at 2^-24 of a value below one).
-            const float2 q = qtab[pl];
-            const float p1 = q.x * bl.kl;
-            sincos_rev(fmaf(q.y, bl.kf, p1 - rintf(p1)), sn, cs);
-            const float cr = crtab[pl], ci = citab[pl];
-            mr[t] = cr * cs + ci * sn;                                  // Re c*exp(-j x)
-            mi[t] = ci * cs - cr * sn;                                  // Im
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) { orr[t] = __shfl_xor(mr[t], 1); oi[t] = __shfl_xor(mi[t], 1); }
-    float gr[4], gi[4];
-    gr[0] = c ? orr[0] : mr[0]; gi[0] = c ? oi[0] : mi[0];
-    gr[1] = c ? orr[1] : mr[1]; gi[1] = c ? oi[1] : mi[1];
-    gr[2] = c ? mr[0] : orr[0]; gi[2] = c ? mi[0] : oi[0];
-    gr[3] = c ? mr[1] : orr[1]; gi[3] = c ? mi[1] : oi[1];
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const float e0 = c ? gi[jj] : gr[jj];                           // row 2l   : Re G (re col) / Im G (im col)
-        const float e1 = c ? gr[jj] : -gi[jj];                          // row 2l+1 : -Im G        / Re G
-        h2 ph, pl2;
-        split2_f16(e0, e1, ph, pl2);
-        Bhi[2 * jj] = ph[0]; Bhi[2 * jj + 1] = ph[1];
-        Blo[2 * jj] = pl2[0]; Blo[2 * jj + 1] = pl2[1];
-    }
-}
 
 // One 32-row tile of one strip: 2*NS ds_read_b128 of A' issued together, 3*NS MFMAs, 16 stores.  NS = K-steps that
 // hold a kept path (8 paths per step); a template parameter so that the body is one straight-line block - with the
@@ -683,7 +593,7 @@ static int64_t resident_grid(const void* kfn, int threads, size_t smem, int64_t 
         (void)hipGetLastError();
         per_cu = 1;
     }
-    int64_t grid = (int64_t)256 * per_cu;
+    int64_t grid = (int64_t)device_cu_count() * per_cu;
     if (items_per_wg > 0) {
         // a few items per workgroup, but never fewer than four grids' worth of workgroups when the work allows it
         // (config 2 = 10k items: 0.43 ms with 2500 workgroups, 0.48 with 1250)
@@ -728,9 +638,10 @@ size_t beam_workspace_bytes(int64_t user_count, int n_beams, int P) {
     return align_up((size_t)user_count * (size_t)n_beams * (size_t)P * 8, 256) + align_up((size_t)user_count * 4, 256);
 }
 
-int launch_channels_fd_beams(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
-                             const float2* codebook, int n_beams, void* beam_ws, float2* out, hipStream_t stream) {
-    if (user_count == 0 || prm.n_selected == 0 || n_beams == 0) return DMX_OK;
+// projection f[b,l] = sum_tx F[b,tx] a_tx[tx,l] of every user into `beam_ws` (beam_workspace_bytes); `tabs` receives the
+// two arrays inside it that the contraction kernels read
+int launch_beam_project(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
+                        const float2* codebook, int n_beams, void* beam_ws, hipStream_t stream, BeamTabs* tabs) {
     BeamArgs b;
     b.user_begin = user_begin;
     b.m_tx = prm.bs_shape[0] * prm.bs_shape[1];
@@ -758,7 +669,18 @@ int launch_channels_fd_beams(const dmx_params& prm, const WsView& ws, int64_t us
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("k2b_beam_project launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
-    return launch_mfma_any(prm, ws, user_begin, user_count, out, 0, n_beams, b.ftab, b.fexp, nullptr, stream);
+    tabs->ftab = b.ftab;
+    tabs->fexp = b.fexp;
+    return DMX_OK;
+}
+
+int launch_channels_fd_beams(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
+                             const float2* codebook, int n_beams, void* beam_ws, float2* out, hipStream_t stream) {
+    if (user_count == 0 || prm.n_selected == 0 || n_beams == 0) return DMX_OK;
+    BeamTabs t;
+    int rc = launch_beam_project(prm, ws, user_begin, user_count, codebook, n_beams, beam_ws, stream, &t);
+    if (rc) return rc;
+    return launch_mfma_any(prm, ws, user_begin, user_count, out, 0, n_beams, t.ftab, t.fexp, nullptr, stream);
 }
 
 static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,

@@ -83,10 +83,12 @@ def gather_users_to_root(local: torch.Tensor, n_total: int, dst: int = 0, group=
             return out
         return local
     dist = _dist()
+    # one batch of point-to-point operations per rank: on RCCL the root's receives from all peers are grouped and
+    # progress concurrently (one direct xGMI link per peer), instead of one blocking receive after the other
+    ops = []
     if rank == dst:
         if out is None:
             out = torch.empty((n_total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        reqs = []
         for r in range(world):
             b, e = shard_bounds(n_total, world, r)
             if e == b:
@@ -94,13 +96,64 @@ def gather_users_to_root(local: torch.Tensor, n_total: int, dst: int = 0, group=
             if r == dst:
                 out[b:e].copy_(local)
             else:
-                reqs.append(dist.irecv(out[b:e], src=r, group=group))
-        for q in reqs:
+                ops.append(dist.P2POp(dist.irecv, out[b:e], r, group))
+    elif local.shape[0] > 0:
+        ops.append(dist.P2POp(dist.isend, local, dst, group))
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
             q.wait()
-        return out
-    if local.shape[0] > 0:
-        dist.send(local, dst=dst, group=group)
-    return None
+    return out if rank == dst else None
+
+
+def macro_shard_plan(n_users: List[int], world: int, rank: int) -> List[Tuple[int, int, int]]:
+    """(basestation, user_begin, user_end) items of rank `rank` for a MacroDataset whose children hold
+    ``n_users[i]`` users each (deepmimo/generator/dataset.py:947-950 runs them one after the other): the children's
+    users are laid end to end and that line is cut into `world` contiguous blocks - both axes are independent, so a
+    rank's block may cover the tail of one basestation and the head of the next.  Every (basestation, user) lands on
+    exactly one rank, loads differ by at most one user."""
+    total = int(sum(n_users))
+    gb, ge = shard_bounds(total, world, rank)
+    plan, start = [], 0
+    for i, n in enumerate(n_users):
+        b, e = max(gb, start), min(ge, start + n)
+        if e > b:
+            plan.append((i, b - start, e - start))
+        start += n
+    return plan
+
+
+def gather_macro_to_root(pieces: Dict[int, torch.Tensor], n_users: List[int], dst: int = 0, group=None) -> Optional[List[torch.Tensor]]:
+    """Bring a MacroDataset's sharded results together on rank `dst`: ``pieces[i]`` is this rank's block of
+    basestation i (as planned by ``macro_shard_plan``; absent when the rank holds none of it).  Returns the list of
+    full per-basestation tensors on `dst` (what MacroDataset.compute_channels returns in one process), None elsewhere.
+    Point-to-point fan-in, one batch per rank, as in ``gather_users_to_root``."""
+    rank, world = _world(group)
+    plans = [macro_shard_plan(n_users, world, r) for r in range(world)]
+    mine = {i: (b, e) for i, b, e in plans[rank]}
+    for i, (b, e) in mine.items():
+        if i not in pieces or pieces[i].shape[0] != e - b:
+            raise ValueError(f"rank {rank}: basestation {i} block must hold {e - b} users")
+    if world == 1:
+        return [pieces[i] for i in range(len(n_users))]
+    dist = _dist()
+    # trailing shape / dtype come from any piece this rank holds; every rank holds at least one unless it has no users
+    ops, outs = [], None
+    if rank == dst:
+        ref = next(iter(pieces.values()))
+        outs = [torch.empty((n,) + tuple(ref.shape[1:]), dtype=ref.dtype, device=ref.device) for n in n_users]
+        for r in range(world):
+            for i, b, e in plans[r]:
+                if r == dst:
+                    outs[i][b:e].copy_(pieces[i])
+                else:
+                    ops.append(dist.P2POp(dist.irecv, outs[i][b:e], r, group))
+    else:
+        for i, b, e in plans[rank]:
+            ops.append(dist.P2POp(dist.isend, pieces[i].contiguous(), dst, group))
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
+    return outs
 
 
 @dataclass
@@ -113,8 +166,12 @@ class ShardResult:
 
 
 def compute_channels_sharded(data, params, bs_fov=None, ue_fov=None, group=None, device_index: Optional[int] = None,
-                             want_side: bool = True, variant: int = 0) -> ShardResult:
+                             want_side: bool = True, variant: int = 0, user_range: Optional[Tuple[int, int]] = None):
     """Each rank generates the channels of its own user block on its own GPU.
+
+    ``data`` may also be a MacroDataset or a list of per-basestation mappings: the (basestation, user) items are then
+    partitioned by ``macro_shard_plan`` and the result is ``{basestation: ShardResult}`` for the blocks this rank owns
+    (``gather_macro_to_root`` assembles the per-basestation list).  ``user_range`` overrides the rank's block.
 
     data: mapping with the full float32 [N, L] ray matrices (every rank may hold the full host
     copy - 800 B per user - or a torch tensor); only the local rows are uploaded.  params:
@@ -124,8 +181,15 @@ def compute_channels_sharded(data, params, bs_fov=None, ue_fov=None, group=None,
     rank, world = _world(group)
     if device_index is None:
         device_index = torch.cuda.current_device()
+    children = data.datasets if hasattr(data, "datasets") else (list(data) if isinstance(data, (list, tuple)) else None)
+    if children is not None:
+        n_users = [int(d[c.POWER_PARAM_NAME].shape[0]) for d in children]
+        return {i: compute_channels_sharded(children[i], params, bs_fov=bs_fov, ue_fov=ue_fov, group=group,
+                                            device_index=device_index, want_side=want_side, variant=variant,
+                                            user_range=(b, e))
+                for i, b, e in macro_shard_plan(n_users, world, rank)}
     n_total = int(data[c.POWER_PARAM_NAME].shape[0])
-    b, e = shard_bounds(n_total, world, rank)
+    b, e = shard_bounds(n_total, world, rank) if user_range is None else user_range
     eng = ChannelEngine(device_index)
     local = {k: data[k][b:e] for k in c.RAY_FIELDS}
     for k in (c.DOPPLER_VEL_PARAM_NAME, c.DOPPLER_ACC_PARAM_NAME):

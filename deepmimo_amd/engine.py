@@ -60,6 +60,20 @@ def is_full_fov(fov) -> bool:
     return fov[0] >= 360 and fov[1] >= 180
 
 
+def uniform_stride(sel: np.ndarray):
+    """(first, stride) when sel[k] == first + k * stride with stride > 0 for every k (dmx_params.sc_stride: lets the
+    library pick the folded kernel without reading the device copy back), else (0, 0)."""
+    sel = np.asarray(sel).astype(np.int64).ravel()
+    if sel.size == 0 or abs(int(sel[0])) >= 2 ** 30:
+        return 0, 0
+    if sel.size == 1:
+        return int(sel[0]), 1
+    d = int(sel[1] - sel[0])
+    if d <= 0 or d >= 2 ** 20 or not np.array_equal(sel, sel[0] + d * np.arange(sel.size)):
+        return 0, 0
+    return int(sel[0]), d
+
+
 class ChannelEngine:
     def __init__(self, device_index: int = 0):
         self.lib = nat.load()
@@ -94,7 +108,8 @@ class ChannelEngine:
 
     # ------------------------------------------------------------------ C structs
     def _params_struct(self, params, bs_fov, ue_fov, ue_rot_per_user: Optional[torch.Tensor],
-                       sel_dev: Optional[torch.Tensor], carrier_freq: float, have_doppler: bool) -> nat.DmxParams:
+                       sel_dev: Optional[torch.Tensor], carrier_freq: float, have_doppler: bool,
+                       sc_hint=(0, 0)) -> nat.DmxParams:
         bs, ue, ofdm = params[c.PARAMSET_ANT_BS], params[c.PARAMSET_ANT_UE], params[c.PARAMSET_OFDM]
         p = nat.DmxParams()
         p.bs_shape[0], p.bs_shape[1] = int(bs[c.PARAMSET_ANT_SHAPE][0]), int(bs[c.PARAMSET_ANT_SHAPE][1])
@@ -137,6 +152,7 @@ class ChannelEngine:
         p.rx_filter = int(bool(ofdm[c.PARAMSET_OFDM_LPF]))
         p.enable_doppler = int(bool(params[c.PARAMSET_DOPPLER_EN]) and have_doppler)
         p.carrier_freq = float(carrier_freq)
+        p.sc_first, p.sc_stride = sc_hint
         return p
 
     def _stream_ptr(self):
@@ -162,7 +178,8 @@ class ChannelEngine:
                 raise ValueError(f"per-user UE rotation must be [n_ue, 3], got {tuple(rot_dev.shape)}")
             keep.append(rot_dev)
         have_dop = rays.doppler_vel is not None and rays.doppler_acc is not None
-        p = self._params_struct(params, bs_fov, ue_fov, rot_dev, sel_dev, carrier_freq, have_dop)
+        p = self._params_struct(params, bs_fov, ue_fov, rot_dev, sel_dev, carrier_freq, have_dop,
+                                sc_hint=uniform_stride(sel))
 
         r = nat.DmxRays()
         r.n_ue, r.n_paths, r.ld = n, L, L
@@ -290,6 +307,37 @@ class ChannelEngine:
                                               C.c_void_p(out.data_ptr()), self._stream_ptr())
                 nat.check(rc, "dmx_channels_td")
         return out
+
+    def beam_power(self, prep: PrepResult, tx_codebook, user_begin: int = 0, user_count: Optional[int] = None,
+                   want_best: bool = True):
+        """dmx_beam_power: the beam-sweep reduction of docs/manual.ipynb cell 105 without any [N, ., K] tensor.
+        Returns (mean_amplitude float32 [user_count, n_beams], best_beam int32 [user_count] or None), both in HBM:
+        mean_amplitude[u, b] = np.abs(F @ H[u]).mean(axis=0).mean(axis=-1)."""
+        p = prep.params_struct
+        if user_count is None:
+            user_count = prep.n_ue - user_begin
+        m_tx = p.bs_shape[0] * p.bs_shape[1]
+        cb = tx_codebook if isinstance(tx_codebook, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(tx_codebook))
+        cb = cb.to(device=self.device, dtype=torch.complex64).contiguous()
+        if cb.dim() != 2 or cb.shape[1] != m_tx or cb.shape[0] < 1:
+            raise ValueError(f"tx_codebook must be [n_beams, {m_tx}], got {tuple(cb.shape)}")
+        if not p.freq_domain or p.rx_filter:
+            raise ValueError("beam_power needs freq_domain = 1 and rx_filter = 0")
+        nb = int(cb.shape[0])
+        amp = torch.empty((user_count, nb), dtype=torch.float32, device=self.device)
+        best = torch.empty((user_count,), dtype=torch.int32, device=self.device) if want_best else None
+        if user_count == 0:
+            return amp, best
+        with torch.cuda.device(self.device):
+            nbytes = int(self.lib.dmx_beam_workspace_bytes(C.byref(p), user_count, prep.n_paths_loaded, nb))
+            bws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+            off = (-bws.data_ptr()) % 256
+            rc = self.lib.dmx_beam_power(C.byref(p), C.c_void_p(prep.workspace.data_ptr()), prep.n_ue, prep.n_paths_loaded,
+                                         user_begin, user_count, C.c_void_p(cb.data_ptr()), nb,
+                                         C.c_void_p(bws.data_ptr() + off), nbytes, C.c_void_p(amp.data_ptr()),
+                                         C.c_void_p(best.data_ptr()) if want_best else None, self._stream_ptr())
+            nat.check(rc, "dmx_beam_power")
+        return amp, best
 
     def pathloss(self, rays: DeviceRays, coherent: bool = True) -> torch.Tensor:
         """dmx_pathloss: float32 [n_ue] dB (dataset.py:541-566)."""

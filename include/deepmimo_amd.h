@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DMX_ABI_VERSION 1
+#define DMX_ABI_VERSION 2
 
 /* status codes (0 = ok).  dmx_last_error() holds the message of the last failure on this thread. */
 #define DMX_OK               0
@@ -82,6 +82,12 @@ typedef struct dmx_params {
     int32_t rx_filter;            /* ofdm.rx_filter (LPF / sinc interpolation)  channel.py:193-194 */
     int32_t enable_doppler;       /* apply the v3 Doppler term (construct_deepmimo.py:267-280) */
     double  carrier_freq;         /* Hz, for Doppler */
+    /* Host-side promise about the DEVICE array above (ABI 2): when sc_stride > 0 the caller guarantees
+     * selected_subcarriers[k] == sc_first + k * sc_stride for every k (np.arange(N), np.arange(0, N, s), [0] ...:
+     * what channel.py:57 and the reference's own scripts select).  It lets dmx_channels_fd pick the folded kernel for
+     * few antenna pairs without reading the device array back.  sc_stride = 0 makes no promise (any selection). */
+    int32_t sc_first;
+    int32_t sc_stride;
 } dmx_params;
 
 /* Optional side products of the path-prep stage (any pointer may be NULL = not wanted).
@@ -127,15 +133,17 @@ int dmx_path_prep(const dmx_rays* rays, const dmx_params* prm, void* workspace, 
  * first of those users (complex64 [user_count, M_rx, M_tx, K]).
  * variant: 0 = automatic; 1 = fp32 vector kernel; 2 = split-precision MFMA kernel (persistent workgroups of 8
  *          waves, two per CU, or of 4 waves up to 128 subcarriers; non-temporal output stores); 9 = small-output
- *          kernel (one wave per user; automatic when few subcarriers are selected).  Tuning knobs kept for A/B
- *          measurements: 3 = MFMA with plain stores (16 waves), 4 / 5 / 10 = 4- / 8- / 16-wave workgroups whatever
- *          the subcarrier count, 8 = one 16-wave workgroup per (user, row block) instead of persistent workgroups,
- *          11 = exactly the resident number of persistent 16-wave workgroups.
+ *          kernel (one wave per user; automatic when few subcarriers are selected); 12 = folded matrix-core kernel
+ *          for at most 64 antenna pairs (needs prm->sc_stride > 0; automatic up to 32 pairs from 32 subcarriers on).
+ *          Tuning knobs kept for A/B measurements (all parity-tested): 3 = MFMA with plain stores (16 waves),
+ *          4 / 5 / 10 = 4- / 8- / 16-wave workgroups whatever the subcarrier count, 8 = one 16-wave workgroup per
+ *          (user, row block) instead of persistent workgroups, 11 = exactly the resident number of persistent
+ *          16-wave workgroups.
  */
 int dmx_channels_fd(const dmx_params* prm, const void* workspace, int64_t n_ue, int32_t n_paths_loaded,
                     int64_t user_begin, int64_t user_count, void* out_c64, int32_t variant, void* stream);
 
-/* Host-only: the kernel `variant = 0` selects for this shape (1, 2 or 9 above), from measured crossovers; negative on
+/* Host-only: the kernel `variant = 0` selects for this shape (1, 2, 9 or 12 above), from measured crossovers; negative on
  * a bad argument.  No GPU involved. */
 int dmx_fd_kernel_choice(const dmx_params* prm, int32_t n_paths_loaded);
 
@@ -161,6 +169,19 @@ size_t dmx_beam_workspace_bytes(const dmx_params* prm, int64_t user_count, int32
 int dmx_channels_fd_beams(const dmx_params* prm, const void* workspace, int64_t n_ue, int32_t n_paths_loaded,
                           int64_t user_begin, int64_t user_count, const void* codebook_c64, int32_t n_beams,
                           void* beam_workspace, size_t beam_workspace_bytes, void* out_c64, void* stream);
+
+/*
+ * Fused consumer that writes no [N, ., K] tensor at all: the beam-sweep reduction of
+ * docs/manual.ipynb cell 105, `np.abs(F1 @ dataset.channel).mean(axis=1).mean(axis=-1)`:
+ *   out_mean_amp[u, b] = 1 / (M_rx K) * sum_rx sum_k | sum_tx F[b,tx] H[u, rx, tx, k] |        float32 [user_count, n_beams]
+ *   out_best_beam[u]   = argmax_b out_mean_amp[u, b] (first maximum; -1 for a user without paths)   int32 [user_count], may be NULL
+ * (cells 110 / 112 take argmax / max of the rounded dBm values 20 log10(.) + 30: the host does that on the small
+ * [N, n_beams] result).  Frequency domain without rx_filter; same workspace as dmx_channels_fd_beams.
+ */
+int dmx_beam_power(const dmx_params* prm, const void* workspace, int64_t n_ue, int32_t n_paths_loaded,
+                   int64_t user_begin, int64_t user_count, const void* codebook_c64, int32_t n_beams,
+                   void* beam_workspace, size_t beam_workspace_bytes, float* out_mean_amp, int32_t* out_best_beam,
+                   void* stream);
 
 /*
  * Stage 2, time domain (replaces channel.py:285-287): out[u, rx, tx, s] = a_rx a_tx sqrt(p) e^{j phase}

@@ -14,32 +14,16 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle_np as onp  # noqa: E402
-from tests.test_gpu_random_sweep import _random_config  # noqa: E402
+from tests._cases import random_case  # noqa: E402
 
 
-def main():
+def main(n_cfg=None):
     import deepmimo as dm
-    n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    if n_cfg is None:
+        n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     worst = 0.0
     for seed in range(n_cfg):
-        rng = np.random.default_rng(9000 + seed)
-        c = _random_config(rng)
-        n = c["n_ue"]
-        rays = onp.synth_rays(n, c["L"], seed=seed, max_delay=c["max_delay"])
-        if c["holes"]:
-            hole = rng.uniform(size=(n, c["L"])) < 0.2
-            for k in onp.RAY_KEYS:
-                rays[k][hole] = np.nan
-        if c["ue_rot_mode"] == "zero":
-            ue_rot = np.zeros(3, int)
-        elif c["ue_rot_mode"] == "const":
-            ue_rot = rng.integers(-90, 91, 3)
-        else:
-            ue_rot = rng.uniform(-60, 60, (n, 3))
-            if n == 3:
-                ue_rot = rng.uniform(-60, 60, (n, 3))
-        if np.ndim(ue_rot) == 2 and ue_rot.shape == (3, 3) and n == 3:
-            pass
+        c, rays, ue_rot, op, bs_fov, ue_fov = random_case(seed)       # the configurations of tests/test_gpu_random_sweep.py
         fd = c["mode"] != "td"
         p = dm.ChannelGenParameters()
         p.bs_antenna.shape, p.ue_antenna.shape = np.array(c["bs"]), np.array(c["ue"])
@@ -49,15 +33,7 @@ def main():
         p.num_paths, p.freq_domain = c["num_paths"], int(fd)
         p.ofdm.subcarriers, p.ofdm.selected_subcarriers = c["N"], np.asarray(c["sel"])
         p.ofdm.bandwidth, p.ofdm.rx_filter = c["bandwidth"], int(c["mode"] == "lpf")
-        op = onp.make_params(
-            bs_antenna=dict(shape=c["bs"], spacing=c["spacing"], rotation=np.array(c["bs_rot"]), radiation_pattern=str(c["bs_pat"])),
-            ue_antenna=dict(shape=c["ue"], spacing=c["spacing"], rotation=np.array(ue_rot), radiation_pattern=str(c["ue_pat"])),
-            num_paths=c["num_paths"], freq_domain=int(fd),
-            ofdm=dict(subcarriers=c["N"], selected_subcarriers=np.asarray(c["sel"]), bandwidth=c["bandwidth"],
-                      rx_filter=int(c["mode"] == "lpf")))
         ds = dm.Dataset({k: v.copy() for k, v in rays.items()})
-        bs_fov = None if c["bs_fov"] is None else np.array(c["bs_fov"])
-        ue_fov = None if c["ue_fov"] is None else np.array(c["ue_fov"])
         if bs_fov is not None or ue_fov is not None:
             kw = {}
             if bs_fov is not None:
@@ -80,6 +56,7 @@ def main():
         assert np.array_equal(res["num_paths"], np_ref), f"seed {seed}: num_paths"
         assert (mask_ref is None and res["_fov_mask"] is None) or np.array_equal(res["_fov_mask"], mask_ref), f"seed {seed}: mask"
     print(f"oracle == reference on {n_cfg} random configurations; worst |dH|/peak = {worst:.2e}")
+    return worst
 
 
 if __name__ == "__main__":

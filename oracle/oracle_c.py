@@ -43,7 +43,8 @@ class Params(C.Structure):
                 ("n_subcarriers", C.c_int32), ("n_selected", C.c_int32),
                 ("selected_subcarriers", C.POINTER(C.c_int32)),
                 ("bandwidth", C.c_double), ("rx_filter", C.c_int32), ("enable_doppler", C.c_int32),
-                ("carrier_freq", C.c_double)]
+                ("carrier_freq", C.c_double),
+                ("sc_first", C.c_int32), ("sc_stride", C.c_int32)]     # ABI 2 hint; the twins read the array itself
 
 
 class Side(C.Structure):

@@ -37,6 +37,21 @@ def main():
         H = ds.compute_channels(p)
         assert np.array_equal(full.numpy(), H), "sharded result differs from the single-process result"
         assert np.array_equal(los.numpy(), ds.los)
+    # MacroDataset x users: two basestations, (basestation, user-block) items partitioned over the ranks
+    rays2 = onp.synth_rays(max(3, n_total // 3), 12, seed=78)
+    p2 = dm.ChannelGenParameters()
+    p2.bs_antenna.shape = np.array([8, 4])
+    p2.ofdm.selected_subcarriers = np.arange(0, 512, 16)
+    md = dm.MacroDataset([dm.Dataset(dict(rays)), dm.Dataset(dict(rays2))])
+    n_users = [n_total, rays2["power"].shape[0]]
+    res = ddist.compute_channels_sharded(md, p2.validate(n_total), device_index=0)
+    assert sorted(res) == [i for i, _, _ in ddist.macro_shard_plan(n_users, world, rank)]
+    full = ddist.gather_macro_to_root({i: r.channel.cpu() for i, r in res.items()}, n_users, dst=0)
+    if rank == 0:
+        want = md.compute_channels(p2)                                  # single-process fan-out: a list
+        assert len(full) == len(want) == 2
+        for got, w in zip(full, want):
+            assert np.array_equal(got.numpy(), w), "sharded MacroDataset differs from the single-process fan-out"
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank} ok")

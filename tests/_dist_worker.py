@@ -33,6 +33,20 @@ def main():
     got = ddist.gather_users_to_root(chan[..., ::2].contiguous(), n_total, dst=world - 1, out=out)
     if rank == world - 1:
         assert got is out and torch.equal(out.real[:, 0, 0, 1], torch.arange(n_total, dtype=torch.float32))
+    # MacroDataset axis: three basestations of different sizes, (basestation, user) items cut over the ranks
+    n_users = [n_total, 3, max(1, n_total // 2)]
+    pieces = {}
+    for i, ub, ue in ddist.macro_shard_plan(n_users, world, rank):
+        uu = torch.arange(ub, ue, dtype=torch.float32)
+        pieces[i] = torch.complex(uu[:, None, None, None] * torch.ones(1, 2, 3, 4) + 1000 * i, torch.zeros(ue - ub, 2, 3, 4))
+    full = ddist.gather_macro_to_root(pieces, n_users, dst=0)
+    if rank == 0:
+        assert len(full) == 3
+        for i, n in enumerate(n_users):
+            assert full[i].shape == (n, 2, 3, 4)
+            assert torch.equal(full[i].real[:, 1, 2, 3], torch.arange(n, dtype=torch.float32) + 1000 * i)
+    else:
+        assert full is None
     # max-over-ranks timing reduction used by bench.py
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -25,6 +25,26 @@ def test_shard_bounds_cover_and_order():
         ddist.shard_bounds(10, 4, 4)
 
 
+def test_macro_shard_plan_partitions_every_basestation_user_once():
+    for n_users in ([5], [4, 4], [10, 1, 7], [0, 3, 0, 9], [100_000, 100_000, 31_931]):
+        for g in (1, 2, 3, 8):
+            seen = [[0] * n for n in n_users]
+            loads = []
+            for r in range(g):
+                plan = ddist.macro_shard_plan(n_users, g, r)
+                loads.append(sum(e - b for _, b, e in plan))
+                assert plan == sorted(plan)
+                for i, b, e in plan:
+                    assert 0 <= b < e <= n_users[i]
+                    if n_users[i] < 1000:
+                        for u in range(b, e):
+                            seen[i][u] += 1
+            assert sum(loads) == sum(n_users) and max(loads) - min(loads) <= -(-sum(n_users) // g)
+            assert all(v == 1 for row in seen if len(row) < 1000 for v in row)
+    assert ddist.macro_shard_plan([4, 4], 2, 0) == [(0, 0, 4)] and ddist.macro_shard_plan([4, 4], 2, 1) == [(1, 0, 4)]
+    assert ddist.macro_shard_plan([3, 5], 2, 0) == [(0, 0, 3), (1, 0, 1)]
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -1,6 +1,7 @@
 """GPU tests at BASELINE.json's full single-GPU sizes (config 2: 10k users x 32x4 x 10 paths x 256 sc;
-config 3 = headline: 100k users x 64x4 x 25 paths x 512 sc, 104.9 GB of output; config 5's per-GPU shard:
-6,250 users x 256x16 x 25 paths x 1024 sc with the Doppler term, 209.7 GB), through the C-ABI.
+config 3 = headline: 100k users x 64x4 x 25 paths x 512 sc, 104.9 GB of output; config 4's per-GPU shard: 125,000
+users of the same shape, 131 GB; config 5's per-GPU shard: 6,250 users x 256x16 x 25 paths x 1024 sc with the Doppler
+term, 209.7 GB; plus DeepMIMO's default-sized arrays at 150-200k users), through the C-ABI.
 
 The oracle cannot run these sizes (the reference itself cannot: SURVEY.md section 6), so parity is
 checked through size-independent properties plus an oracle comparison on a user sample:
@@ -22,7 +23,12 @@ pytestmark = pytest.mark.gpu
 CONFIGS = {
     "c2": dict(n_ue=10_000, bs=[8, 4], ue=[2, 2], L=10, N=256),
     "c3": dict(n_ue=100_000, bs=[8, 8], ue=[2, 2], L=25, N=512),
+    # config 4 = 1M users over 8 GPUs: its per-GPU shard, 125,000 users, 131 GB of output in one launch
+    "c4": dict(n_ue=125_000, bs=[8, 8], ue=[2, 2], L=25, N=512),
     "c5": dict(n_ue=6_250, bs=[16, 16], ue=[4, 4], L=25, N=1024, doppler=True, sample=10, perm_users=160),
+    # DeepMIMO's default arrays (channel.py:36-46) at scale: the folded matrix-core kernel is the automatic choice
+    "d8": dict(n_ue=200_000, bs=[8, 1], ue=[1, 1], L=25, N=512),
+    "d16": dict(n_ue=150_000, bs=[4, 4], ue=[1, 1], L=25, N=256),
 }
 
 
@@ -64,7 +70,7 @@ FC = 3.5e9          # carrier for the Doppler term of config 5
 RAY_AND_DOPPLER = ("doppler_vel", "doppler_acc")
 
 
-@pytest.mark.parametrize("cfg", ["c2", "c3", "c5"])
+@pytest.mark.parametrize("cfg", ["c2", "c3", "c4", "c5", "d8", "d16"])
 def test_full_size_properties(cfg):
     w, rays, p, op, eng, onp = _setup(cfg)
     n = w["n_ue"]

@@ -49,11 +49,16 @@ def _dataset(case, rays, with_doppler=False):
     return ds
 
 
-@pytest.mark.parametrize("variant", [1, 0, 4, 5])
+@pytest.mark.parametrize("variant", [1, 0, 4, 5, 12])
 @pytest.mark.parametrize("name", golden_names())
 def test_golden(name, variant, capsys):
     import deepmimo_amd as dm
     case, rays, ue_rot, ref = load_golden(name)
+    if variant == 12:
+        from deepmimo_amd.engine import uniform_stride
+        pairs = int(np.prod(case["bs_shape"]) * np.prod(case["ue_shape"]))
+        if not (case["freq_domain"] and not case["rx_filter"] and pairs <= 64 and uniform_stride(np.array(case["selected"]))[1] > 0):
+            pytest.skip("not a case of the folded kernel")
     dm.config("fd_kernel_variant", variant)
     try:
         ds = _dataset(case, rays)
@@ -155,8 +160,36 @@ def _small_kernel_fits(shape):
     return (bs[0] * bs[1] + ue[0] * ue[1] + len(sel)) * min(L, 32) * 8 <= 156 * 1024
 
 
-@pytest.mark.parametrize("variant", [1, 0, 4, 5, 9])
-@pytest.mark.parametrize("shape", SHAPES + SHAPES_SMALL, ids=[f"s{i}" for i in range(len(SHAPES) + len(SHAPES_SMALL))])
+SHAPES_FOLD = [
+    # few antenna pairs x uniformly spaced subcarriers - the folded matrix-core kernel's regime (variant 12);
+    # DeepMIMO's default arrays are BS 8x1 / UE 1x1 (channel.py:36-46)
+    (45, 25, [8, 1], [1, 1], 64, list(range(64)), {}),                                  # 8 pairs: 4 blocks per 32-row tile
+    (31, 25, [8, 1], [1, 1], 512, list(range(512)), dict(max_delay=40e-6)),             # 32 blocks = one full chunk
+    (23, 10, [4, 4], [1, 1], 256, list(range(256)), dict(bs_rot=[5, -20, 60])),         # 16 pairs
+    (19, 25, [8, 2], [2, 1], 512, list(range(0, 512, 2)), dict(all_valid=True, max_delay=45e-6)),   # 32 pairs, stride 2
+    (17, 7, [4, 3], [1, 1], 100, list(range(100)), {}),                                 # 12 pairs (rows straddle tiles), K % 16 = 4
+    (13, 32, [5, 1], [1, 1], 2048, list(range(7, 2048, 3)), dict(max_delay=95e-6)),     # 5 pairs, K = 681: several chunks + tail, first != 0
+    (9, 25, [8, 4], [2, 1], 128, list(range(128)), dict(ue_rot=[10, 20, 30])),          # 64 pairs: the kernel's upper limit
+    (12, 25, [2, 1], [1, 1], 1024, list(range(1024)), dict(all_valid=True, max_delay=90e-6)),   # 2 pairs: 16 blocks per tile
+    (11, 3, [8, 1], [1, 1], 64, list(range(10, 43)), {}),                               # K = 33: a lone subcarrier in the last block
+    (10, 25, [1, 1], [1, 1], 4096, list(range(4096)), dict(all_valid=True, max_delay=300e-6)),  # one pair, 4096 subcarriers
+]
+
+
+def _fold_applicable(shape):
+    n, L, bs, ue, N, sel, extra = shape
+    from deepmimo_amd.engine import uniform_stride
+    return uniform_stride(np.asarray(sel))[1] > 0 and bs[0] * bs[1] * ue[0] * ue[1] <= 64
+
+
+ALL_SHAPES = SHAPES + SHAPES_SMALL + SHAPES_FOLD
+
+
+# 1 fp32 vector, 0 automatic, 4 / 5 / 10 matrix cores in 4- / 8- / 16-wave workgroups, 9 small-output, 12 folded, and the
+# measurement knobs of the C-ABI (3 plain stores, 8 one workgroup per item, 11 resident grid): every variant the header
+# documents is parity-checked
+@pytest.mark.parametrize("variant", [1, 0, 4, 5, 9, 12, 3, 8, 10, 11])
+@pytest.mark.parametrize("shape", ALL_SHAPES, ids=[f"s{i}" for i in range(len(ALL_SHAPES))])
 def test_vs_oracle_shapes(shape, variant):
     """Seeded synthetic rays at ragged shapes (K not a multiple of 64, odd panels, 1..32 paths)."""
     import deepmimo_amd as dm
@@ -164,6 +197,10 @@ def test_vs_oracle_shapes(shape, variant):
     n, L, bs, ue, N, sel, extra = shape
     if variant == 9 and not _small_kernel_fits(shape):
         pytest.skip("one user's factor tables exceed the LDS of the small-output kernel")
+    if variant == 12 and not _fold_applicable(shape):
+        pytest.skip("the folded kernel needs uniformly spaced subcarriers and at most 64 antenna pairs")
+    if variant in (3, 8, 10, 11) and shape not in SHAPES[2:7] + SHAPES_FOLD[3:5]:
+        pytest.skip("measurement knobs are checked on a subset of the shapes")
     rays = onp.synth_rays(n, L, seed=1000 + n, all_valid=extra.get("all_valid", False),
                           max_delay=extra.get("max_delay", 2e-6))
     case = dict(bs_shape=bs, ue_shape=ue, bs_spacing=0.5, ue_spacing=0.37, bs_rot=extra.get("bs_rot", [0, 0, 0]),
@@ -416,6 +453,70 @@ def test_beam_codebook_projection(cfg):
         ds.compute_beam_channels(np.ones((4, m_tx + 1)), p)
 
 
+@pytest.mark.parametrize("cfg", [dict(bs=[32, 1], ue=[1, 1], nb=16, L=9, rot=[0, 0, -135], sel=np.arange(0, 512, 7)),   # the notebook's sweep
+                                 dict(bs=[8, 8], ue=[2, 2], nb=64, L=25, rot=[0, 0, 0], sel=np.arange(0, 512, 5)),     # 256 rows: 8 tiles
+                                 dict(bs=[4, 2], ue=[3, 1], nb=5, L=4, rot=[10, 20, 30], sel=np.array([3])),          # 15 rows, one subcarrier
+                                 dict(bs=[8, 4], ue=[4, 3], nb=33, L=32, rot=[0, 0, 0], sel=np.arange(100, 400)),       # 396 rows: two row blocks
+                                 dict(bs=[8, 1], ue=[1, 1], nb=3, L=12, rot=[0, 0, 0], sel=np.arange(512))])           # default arrays
+def test_beam_power_fused_reduction(cfg):
+    """dmx_beam_power / Dataset.compute_beam_power: np.abs(F @ H).mean(axis=1).mean(axis=-1) -> dBm -> argmax
+    (docs/manual.ipynb cells 105, 110, 112) without H or F @ H ever being written; against the oracle's H reduced in
+    float64.  Mean amplitudes rtol 1e-5; dBm within one rounding step; best beam exact except near-ties."""
+    import deepmimo_amd as dm
+    from deepmimo_amd.dataset import _engine
+    from oracle import oracle_np as onp
+    n = 70
+    rays = onp.synth_rays(n, cfg["L"], seed=56)
+    p = dm.ChannelGenParameters()
+    p.bs_antenna.shape, p.ue_antenna.shape = np.array(cfg["bs"]), np.array(cfg["ue"])
+    p.bs_antenna.rotation = np.array(cfg["rot"])
+    p.num_paths = cfg["L"]
+    p.ofdm.selected_subcarriers = cfg["sel"]
+    op = onp.make_params(bs_antenna=dict(shape=cfg["bs"], rotation=np.array(cfg["rot"])), ue_antenna=dict(shape=cfg["ue"]),
+                         num_paths=cfg["L"], ofdm=dict(selected_subcarriers=cfg["sel"]))
+    ref = onp.compute_channels(rays, op)
+    Href = ref["channel"].astype(np.complex128)
+    m_tx = cfg["bs"][0] * cfg["bs"][1]
+    F1 = np.array([dm.steering_vec(np.array(cfg["bs"]), phi=azi).squeeze() for azi in np.around(np.linspace(-60, 60, cfg["nb"]), 2)])
+    F1 = F1.reshape(cfg["nb"], m_tx)
+    rng = np.random.default_rng(2)
+    F2 = (rng.normal(size=(cfg["nb"], m_tx)) + 1j * rng.normal(size=(cfg["nb"], m_tx))) * 11.0
+    for F in (F1, F2):
+        want_amp = np.abs(F @ Href).mean(axis=1).mean(axis=-1)                  # [n, nb] float64
+        ds = dm.Dataset(dict(rays))
+        pwr, best = ds.compute_beam_power(F, p, return_best=True)
+        amp = ds["beam_mean_amplitude"]
+        assert amp.shape == (n, cfg["nb"]) and amp.dtype == np.float32 and pwr.dtype == np.float64
+        np.testing.assert_array_equal(ds.los, ref["los"])
+        has = ref["los"] != -1
+        assert has.sum() > 0 and (~has).sum() > 0
+        np.testing.assert_allclose(amp[has], want_amp[has], rtol=1e-5, atol=0)
+        assert np.all(amp[~has] == 0)
+        # cells 105 / 110 / 112 on the reference amplitudes
+        want_pwr = np.zeros((n, cfg["nb"])) * np.nan
+        want_pwr[has] = np.around(20 * np.log10(want_amp[has]) + 30, 1)
+        assert np.array_equal(np.isnan(pwr), np.isnan(want_pwr))
+        assert np.nanmax(np.abs(pwr - want_pwr)) <= 0.1 + 1e-9                  # a value on a rounding boundary may step
+        assert np.mean(pwr[has] == want_pwr[has]) > 0.98
+        want_best = np.argmax(want_pwr, axis=1).astype(float)
+        want_best[~has] = np.nan
+        assert np.array_equal(np.isnan(best), np.isnan(want_best))
+        for u in np.nonzero(has & (best != want_best))[0]:                       # only (near-)ties may differ
+            assert abs(want_pwr[u, int(best[u])] - want_pwr[u, int(want_best[u])]) <= 0.1 + 1e-9
+        # the kernel's own argmax (first maximum of the un-rounded means)
+        eng = _engine()
+        prep = eng.prepare(eng.upload_rays(rays), p.validate(n))
+        amp_d, best_d = eng.beam_power(prep, F)
+        np.testing.assert_array_equal(amp_d.cpu().numpy(), amp)
+        bd = best_d.cpu().numpy()
+        assert np.all(bd[~has] == -1) and np.array_equal(bd[has], np.argmax(amp[has], axis=1))
+        # a user sub-range is bit-identical to the same rows of the full call (what sharding relies on)
+        part, _ = eng.beam_power(prep, F, user_begin=11, user_count=30)
+        np.testing.assert_array_equal(part.cpu().numpy(), amp[11:41])
+    with pytest.raises(ValueError):
+        ds.compute_beam_power(np.ones((4, m_tx + 1)), p)
+
+
 def test_pathloss_matches_reference_formula():
     """Dataset.compute_pathloss (dataset.py:541-566), restated inline in NumPy with the reference's dtypes."""
     import deepmimo_amd as dm
@@ -486,6 +587,118 @@ def test_sionna_export_of_time_domain_channels():
     md.compute_channels(p)
     with pytest.raises(ValueError):
         DeepMIMOSionnaAdapter(md)
+
+
+def _aux(name):
+    from tests._cases import GOLDEN_DIR
+    return np.load(os.path.join(GOLDEN_DIR, name), allow_pickle=False)
+
+
+def test_pathloss_reference_golden():
+    """Dataset.compute_pathloss against what the REAL reference returned (tests/golden/aux_pathloss.npz, produced by
+    oracle/gen_aux_golden.py from deepmimo/generator/dataset.py:541-566), coherent and incoherent."""
+    import deepmimo_amd as dm
+    z = _aux("aux_pathloss.npz")
+    n, L = z["ray_power"].shape
+    rays = dict(power=z["ray_power"], phase=z["ray_phase"])
+    for k in dm.consts.RAY_FIELDS:
+        rays.setdefault(k, np.zeros((n, L), np.float32))
+    ds = dm.Dataset(rays)
+    for coherent, key in ((True, "ref_coherent"), (False, "ref_incoherent")):
+        want = z[key]
+        got = ds.compute_pathloss(coherent)
+        assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(want).sum() > 0
+        np.testing.assert_allclose(got[~np.isnan(want)], want[~np.isnan(want)], rtol=0, atol=2e-4)   # dB
+
+
+def test_sionna_adapter_reference_golden():
+    """(a, tau) of this package's adapter on GPU-generated TD channels against the samples the REFERENCE's
+    DeepMIMOSionnaAdapter (integrations/sionna_adapter.py:22-200) produced from the reference's own TD channels of
+    the same rays (tests/golden/aux_sionna.npz)."""
+    import deepmimo_amd as dm
+    from deepmimo_amd.sionna_adapter import DeepMIMOSionnaAdapter
+    z = _aux("aux_sionna.npz")
+    rays = [{k[len(f"bs{b}_ray_"):]: z[k] for k in z.files if k.startswith(f"bs{b}_ray_")} for b in range(2)]
+    p = dm.ChannelGenParameters()
+    p.bs_antenna.shape, p.ue_antenna.shape = np.array([4, 2]), np.array([2, 1])
+    p.bs_antenna.rotation = np.array([0, 10, -20])
+    p.num_paths, p.freq_domain = 5, 0
+    md = dm.MacroDataset([dm.Dataset(dict(r)) for r in rays])
+    H = md.compute_channels(p)
+    for b in range(2):
+        assert_channel_close(H[b], z[f"td_channel_bs{b}"], what=f"TD channel of BS {b}")
+    ad = DeepMIMOSionnaAdapter(md, bs_idx=z["bs_idx"], ue_idx=z["ue_idx"])
+    assert len(ad) == int(z["n_samples"])
+    samples = list(ad())
+    a, tau = np.stack([s[0] for s in samples]), np.stack([s[1] for s in samples])
+    assert a.shape == z["a"].shape and a.dtype == z["a"].dtype and tau.dtype == z["tau"].dtype
+    np.testing.assert_array_equal(tau, z["tau"])
+    peak = np.abs(z["a"]).max()
+    assert np.abs(a - z["a"]).max() <= TOL_REL * peak
+    ad1 = DeepMIMOSionnaAdapter(md)                                           # defaults: BS 0, every user
+    assert len(ad1) == int(z["n_samples_default"])
+    s1 = list(ad1())
+    np.testing.assert_array_equal(np.stack([s[1] for s in s1]), z["tau_default"])
+    assert np.abs(np.stack([s[0] for s in s1]) - z["a_default"]).max() <= TOL_REL * np.abs(z["a_default"]).max()
+
+
+def test_only_radiation_pattern_changes_reference_golden():
+    """The reference keeps its cached `_power_linear_ant_gain` when only a radiation pattern changes (its cache is
+    dropped by rotation / FoV changes only, dataset.py:213-220): on the same Dataset the 'dipole' call returns the
+    ISOTROPIC channel again (tests/golden/aux_stale_cache.npz records that, and the fresh dipole result).  This
+    package recomputes by default - a documented deviation, asserted here - and reproduces the reference's sequence
+    exactly under config('strict_reference_cache', True)."""
+    import deepmimo_amd as dm
+    z = _aux("aux_stale_cache.npz")
+    rays = {k[4:]: z[k] for k in z.files if k.startswith("ray_")}
+    assert np.array_equal(z["ref_iso"], z["ref_dipole_same_dataset"])         # what the reference does
+    assert not np.array_equal(z["ref_dipole_fresh"], z["ref_iso"])
+
+    def params(pattern):
+        p = dm.ChannelGenParameters()
+        p.bs_antenna.shape, p.ue_antenna.shape = np.array([4, 2]), np.array([2, 1])
+        p.bs_antenna.rotation = np.array([10, 20, 30])
+        p.bs_antenna.radiation_pattern = pattern
+        p.ofdm.subcarriers = 64
+        p.ofdm.selected_subcarriers = np.arange(0, 64, 4)
+        return p
+
+    # default: the new pattern takes effect at once (deviation)
+    ds = dm.Dataset({k: v.copy() for k, v in rays.items()})
+    assert_channel_close(ds.compute_channels(params("isotropic")), z["ref_iso"], what="isotropic")
+    assert_channel_close(ds.compute_channels(params("halfwave-dipole")), z["ref_dipole_fresh"], what="dipole, recomputed")
+    # strict: the reference's sequence, stale value included
+    dm.config("strict_reference_cache", True)
+    try:
+        ds = dm.Dataset({k: v.copy() for k, v in rays.items()})
+        assert_channel_close(ds.compute_channels(params("isotropic")), z["ref_iso"], what="strict: isotropic")
+        assert_channel_close(ds.compute_channels(params("halfwave-dipole")), z["ref_dipole_same_dataset"], what="strict: stale")
+        np.testing.assert_allclose(ds["_power_linear_ant_gain"], z["ref_gain_same_dataset"], rtol=2e-6, equal_nan=True)
+        ds.apply_fov()
+        assert_channel_close(ds.compute_channels(params("halfwave-dipole")), z["ref_dipole_after_apply_fov"], what="strict: after apply_fov")
+    finally:
+        dm.config("strict_reference_cache", False)
+
+
+def test_steering_codebook_reference_golden():
+    """dm.steering_vec against the reference's vectors (tests/golden/aux_steering.npz, geometry.py:322-339), and a
+    codebook of those REFERENCE vectors through the fused beam-space kernel against F @ H of the oracle."""
+    import deepmimo_amd as dm
+    from oracle import oracle_np as onp
+    z = _aux("aux_steering.npz")
+    rows = {}
+    for i, (mh, mv, phi, theta, spacing) in enumerate(z["cases"]):
+        v = dm.steering_vec(np.array([int(mh), int(mv)]), phi=phi, theta=theta, spacing=spacing)
+        assert v.shape == z[f"v{i}"].shape
+        assert np.abs(v - z[f"v{i}"]).max() <= 1e-12
+        rows.setdefault((int(mh), int(mv)), []).append(z[f"v{i}"].squeeze())
+    F = np.array(rows[(8, 1)])                                               # three reference beams of the 8x1 default array
+    rays = onp.synth_rays(50, 12, seed=77)
+    p = dm.ChannelGenParameters()
+    p.ofdm.selected_subcarriers = np.arange(0, 512, 16)
+    Href = onp.compute_channels(rays, onp.make_params(ofdm=dict(selected_subcarriers=np.arange(0, 512, 16))))["channel"]
+    Y = dm.Dataset(dict(rays)).compute_beam_channels(F, p)
+    assert_channel_close(Y, (F @ Href.astype(np.complex128)).astype(np.complex64), what="reference steering codebook")
 
 
 def test_iter_channels_chunks_equal_full_tensor():

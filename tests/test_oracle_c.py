@@ -103,4 +103,4 @@ def test_twin_structs_have_the_product_layout():
     lib = oc.load()
     for sym in oc.SYMBOLS:
         getattr(lib, sym)
-    assert lib.dmx_cpu_version() == 1
+    assert lib.dmx_cpu_version() == nat.ABI_VERSION

@@ -1,6 +1,8 @@
 """CPU tests: the NumPy oracle (oracle/oracle_np.py) against the golden vectors produced by the
 real reference (oracle/gen_golden.py).  This is what "pins" the oracle: channels must agree to
 1e-12 absolute (the oracle follows the reference's dtype flow), integer side products exactly."""
+import os
+
 import numpy as np
 import pytest
 
@@ -186,3 +188,63 @@ def test_batch_forms_equal_scalar_forms():
             else:
                 np.testing.assert_allclose(a[i, :, l], onp.array_response_scalar([4, 2], 0.5, tb[i, l], pb[i, l]),
                                            rtol=1e-10, atol=1e-12)          # test_array_response.py: rtol 1e-10
+
+
+# ---- the committed recipes must keep running (crosscheck_reference.py had rotted unnoticed) -------------
+ORACLE_SCRIPTS = ("gen_golden", "gen_p2m_golden", "gen_sequence_golden", "gen_aux_golden", "crosscheck_reference",
+                  "certify_baseline", "oracle_np", "oracle_c")
+REFERENCE = "/root/reference"
+
+
+def test_every_oracle_script_imports():
+    """Importing executes no reference code (each script imports `deepmimo` inside main()), so this runs anywhere."""
+    import importlib
+    import glob
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    found = sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(here, "*.py")) if not p.endswith("__init__.py"))
+    assert found == sorted(ORACLE_SCRIPTS), f"update ORACLE_SCRIPTS: {found}"
+    for name in ORACLE_SCRIPTS:
+        mod = importlib.import_module("oracle." + name)
+        assert name in ("oracle_np", "oracle_c") or callable(getattr(mod, "main"))
+
+
+def _run_recipe(script, *args, timeout=600):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=f"{REFERENCE}:{root}", PYTHONDONTWRITEBYTECODE="1", MPLBACKEND="Agg")
+    return subprocess.run([sys.executable, os.path.join(root, "oracle", script), *args], cwd="/tmp", env=env,
+                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="the reference exists in the build container only")
+def test_crosscheck_against_imported_reference():
+    """oracle_np vs the imported reference on the first random configurations of the GPU sweep: bit-identical."""
+    r = _run_recipe("crosscheck_reference.py", "10")
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "oracle == reference on 10 random configurations; worst |dH|/peak = 0.00e+00" in r.stdout
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="the reference exists in the build container only")
+def test_aux_goldens_regenerate_bit_identically(tmp_path):
+    """tests/golden/aux_*.npz are what the reference returns today (the generator is deterministic)."""
+    import shutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = os.path.join(root, "tests", "golden")
+    names = ["aux_steering.npz", "aux_pathloss.npz", "aux_sionna.npz", "aux_stale_cache.npz"]
+    keep = {n: dict(np.load(os.path.join(gold, n))) for n in names}
+    backup = tmp_path / "backup"
+    backup.mkdir()
+    for n in names:
+        shutil.copy(os.path.join(gold, n), backup / n)
+    try:
+        r = _run_recipe("gen_aux_golden.py")
+        assert r.returncode == 0, r.stdout[-2000:]
+        for n in names:
+            new = np.load(os.path.join(gold, n))
+            assert sorted(new.files) == sorted(keep[n])
+            for k in new.files:
+                assert np.array_equal(new[k], keep[n][k], equal_nan=True), (n, k)
+    finally:
+        for n in names:                                            # leave the committed bytes untouched
+            shutil.copy(backup / n, os.path.join(gold, n))
