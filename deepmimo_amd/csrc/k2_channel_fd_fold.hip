@@ -52,11 +52,26 @@ struct FoldArgs {
     int k_tail;        // K - 16*(nblk-1): valid subcarriers of the last block (1..16)
 };
 
+typedef float fv2 __attribute__((ext_vector_type(2)));
+
+// x = hi + lo in f16.  The residual x - hi is ONE mixed-precision fma per value: v_fma_mix_f32 reads the f16 half of
+// the packed register directly (op_sel_hi marks the operand as f16, op_sel picks the half) - the compiler's own form
+// is v_cvt_f32_f16 + v_sub_f32, two instructions per value in a kernel whose time is its VALU count.
 __device__ __forceinline__ void fold_split2(float x0, float x1, fh2& hi, fh2& lo) {
     const fhp2 h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-    const fhp2 l = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
+    const unsigned hb = __builtin_bit_cast(unsigned, h);
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hb), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "v"(x1));
+    const fhp2 l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
     hi = __builtin_bit_cast(fh2, h);
     lo = __builtin_bit_cast(fh2, l);
+}
+
+// (a + jb)(c + jd) as two packed instructions: [ac, ad] then fma([-b, b], [d, c], .)
+__device__ __forceinline__ fv2 fold_cmul(float a, float b, float c, float d) {
+    const fv2 t = fv2{a, a} * fv2{c, d};
+    return __builtin_elementwise_fma(fv2{-b, b}, fv2{d, c}, t);
 }
 
 // a wave's own LDS writes are visible to its later reads (DS operations of one wave execute in order); the compiler
@@ -76,7 +91,11 @@ __global__ __launch_bounds__(256, 4) void k2_fd_fold(WsView ws, FoldArgs a, floa
     uint32_t* rowoff1 = rowoff0 + a.tab_rows;                              // [tab_rows] same for the last chunk
     uint32_t* rowsrc = rowoff1 + a.tab_rows;                               // [tab_rows] (E1 row | Ac row << 16) byte offsets
     uint32_t* pidx = rowsrc + a.tab_rows;                                  // [M] element indices of pair p, 4 x u8
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wave index is uniform by construction; saying so keeps everything derived from it - the work item, its
+    // pointers, the output buffer descriptor, the path count - in scalar registers (a descriptor in vector registers
+    // makes every buffer_store a readfirstlane waterfall loop)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned char* wbase = smem + fold_static_bytes(a.tab_rows, a.M) + (size_t)wave * fold_wave_bytes(a.M, a.ch);
     float2* qtab = reinterpret_cast<float2*>(wbase);                       // [32] q_l as (multiple of 2^-12, remainder)
     unsigned char* Ac = wbase + 256;                                       // [M][FOLD_TROW]  c_l a_rx a_tx (scaled)
@@ -193,7 +212,7 @@ __global__ __launch_bounds__(256, 4) void k2_fd_fold(WsView ws, FoldArgs a, floa
 
         // ---- row tiles: 32 rows (a,p) each
         const uint32_t* rowoff = last ? rowoff1 : rowoff0;
-        const uint32_t lmask = last ? lmask_last : 0x7FFFFFFFu;
+        const bool masked = last && a.k_tail < 16;
         const int rows = nb * M;
         const int ntiles = (rows + 31) >> 5;
         const __amdgpu_buffer_rsrc_t orsrc =
@@ -214,13 +233,17 @@ __global__ __launch_bounds__(256, 4) void k2_fd_fold(WsView ws, FoldArgs a, floa
                     const float4 y1 = *reinterpret_cast<const float4*>(erow + s * 64 + 16);
                     fh8 Ah, Al;
                     fh2 ph, pl;
-                    fold_split2(x0.x * y0.x - x0.y * y0.y, x0.x * y0.y + x0.y * y0.x, ph, pl);
+                    fv2 z = fold_cmul(x0.x, x0.y, y0.x, y0.y);
+                    fold_split2(z[0], z[1], ph, pl);
                     Ah[0] = ph[0]; Ah[1] = ph[1]; Al[0] = pl[0]; Al[1] = pl[1];
-                    fold_split2(x0.z * y0.z - x0.w * y0.w, x0.z * y0.w + x0.w * y0.z, ph, pl);
+                    z = fold_cmul(x0.z, x0.w, y0.z, y0.w);
+                    fold_split2(z[0], z[1], ph, pl);
                     Ah[2] = ph[0]; Ah[3] = ph[1]; Al[2] = pl[0]; Al[3] = pl[1];
-                    fold_split2(x1.x * y1.x - x1.y * y1.y, x1.x * y1.y + x1.y * y1.x, ph, pl);
+                    z = fold_cmul(x1.x, x1.y, y1.x, y1.y);
+                    fold_split2(z[0], z[1], ph, pl);
                     Ah[4] = ph[0]; Ah[5] = ph[1]; Al[4] = pl[0]; Al[5] = pl[1];
-                    fold_split2(x1.z * y1.z - x1.w * y1.w, x1.z * y1.w + x1.w * y1.z, ph, pl);
+                    z = fold_cmul(x1.z, x1.w, y1.z, y1.w);
+                    fold_split2(z[0], z[1], ph, pl);
                     Ah[6] = ph[0]; Ah[7] = ph[1]; Al[6] = pl[0]; Al[7] = pl[1];
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bhi[s], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Blo[s], acc, 0, 0, 0);
@@ -229,13 +252,24 @@ __global__ __launch_bounds__(256, 4) void k2_fd_fold(WsView ws, FoldArgs a, floa
             }
             // accumulator register i is row (i&3) + 8*(i>>2) + 4*(lane>>5) of the tile, column lane&31
             const uint4* ro4 = reinterpret_cast<const uint4*>(rowoff + (rt << 5) + 4 * hh);
+            if (masked) {                                                  // wave-uniform: partial last block in this item
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const uint4 ro = ro4[2 * g];
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * g + 0] * oscale), orsrc, lane_col + (ro.x & lmask), 0, NT ? 2 : 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * g + 1] * oscale), orsrc, lane_col + (ro.y & lmask), 0, NT ? 2 : 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * g + 2] * oscale), orsrc, lane_col + (ro.z & lmask), 0, NT ? 2 : 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * g + 3] * oscale), orsrc, lane_col + (ro.w & lmask), 0, NT ? 2 : 0);
+                for (int g = 0; g < 4; ++g) {
+                    const uint4 ro = ro4[2 * g];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * g + 0] * oscale), orsrc, lane_col + (ro.x & lmask_last), 0, NT ? 2 : 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * g + 1] * oscale), orsrc, lane_col + (ro.y & lmask_last), 0, NT ? 2 : 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * g + 2] * oscale), orsrc, lane_col + (ro.z & lmask_last), 0, NT ? 2 : 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * g + 3] * oscale), orsrc, lane_col + (ro.w & lmask_last), 0, NT ? 2 : 0);
+                }
+            } else {                                                       // rows past the item carry 0xC0000000: out of range as they are
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint4 ro = ro4[2 * g];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * g + 0] * oscale), orsrc, lane_col + ro.x, 0, NT ? 2 : 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * g + 1] * oscale), orsrc, lane_col + ro.y, 0, NT ? 2 : 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * g + 2] * oscale), orsrc, lane_col + ro.z, 0, NT ? 2 : 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * g + 3] * oscale), orsrc, lane_col + ro.w, 0, NT ? 2 : 0);
+                }
             }
         }
     }

@@ -39,8 +39,16 @@ __host__ __device__ inline size_t beam_pow_lds_bytes(int M) {
     return (size_t)BP_WAVES * BP_SLOT + LPAD * (8 + 4 + 4) + 16 + nblk * BP_WAVES * 32 * 4;
 }
 
-__device__ __forceinline__ float dpp_xor1(float v) {           // value of the neighbouring lane (lane ^ 1): quad_perm [1,0,3,2]
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+// v[i] += (v[i] of the neighbouring lane, lane ^ 1) for the 16 squared accumulator values: one VALU instruction each
+// with the DPP operand folded in (quad_perm [1,0,3,2]; the compiler's own form of `v + dpp(v)` is v_mov_b32_dpp + add).
+// A VGPR written by a VALU instruction needs two wait states before a DPP read: one s_nop for the whole group, inside
+// the statement (the compiler pads nothing in front of an asm string).
+#define BP_DPP(n) "v_add_f32_dpp %" #n ", %" #n ", %" #n " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+__device__ __forceinline__ void pair_sums16(float (&v)[16]) {
+    asm("s_nop 1\n\t" BP_DPP(0) BP_DPP(1) BP_DPP(2) BP_DPP(3) BP_DPP(4) BP_DPP(5) BP_DPP(6) BP_DPP(7)
+        BP_DPP(8) BP_DPP(9) BP_DPP(10) BP_DPP(11) BP_DPP(12) BP_DPP(13) BP_DPP(14) BP_DPP(15)
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+          "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
 }
 
 __global__ __launch_bounds__(BP_WAVES * 64, 4) void k2c_beam_power(WsView ws, BeamPowArgs a, int64_t user_count) {
@@ -53,7 +61,8 @@ __global__ __launch_bounds__(BP_WAVES * 64, 4) void k2c_beam_power(WsView ws, Be
     float* misc = citab + LPAD;                                                      // [4]
     float* rs = misc + 4;                                          // [nblk][8 waves][32] partial row sums of |Y| (no atomics:
                                                                    // the summation order is fixed, results are reproducible)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform: tile / strip assignments stay scalar
     const int col = lane & 31, hh = lane >> 5;
     const int B = a.n_beams, M = a.M, P = ws.P;
     const size_t twoK = (size_t)2 * a.K;
@@ -164,11 +173,12 @@ __global__ __launch_bounds__(BP_WAVES * 64, 4) void k2c_beam_power(WsView ws, Be
                             }
                         }
                         // |Y| of the (re, im) lane pair; both lanes of a pair add the same value (halved at the end)
+                        float sq[16];
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const float v = acc[i] * acc[i];
-                            rowsum[i] += __builtin_amdgcn_sqrtf(v + dpp_xor1(v));
-                        }
+                        for (int i = 0; i < 16; ++i) sq[i] = acc[i] * acc[i];
+                        pair_sums16(sq);
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) rowsum[i] += __builtin_amdgcn_sqrtf(sq[i]);
                     }
                 }
             }

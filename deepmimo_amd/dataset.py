@@ -194,31 +194,43 @@ class Dataset(DotDict):
         self._data[_PATTERNS_IN_EFFECT] = pats
         return params
 
-    def _run_prep(self, want_side: bool = True):
-        """Stage 1 on the GPU; refreshes every per-path side product in the cache."""
+    def _run_prep(self, want_side=True):
+        """Stage 1 on the GPU; refreshes every per-path side product in the cache.  want_side="light" computes LoS,
+        path counts and the FoV mask beside the records and leaves the rotated angles / powers to a second stage-1
+        pass that runs only if one of them is ever read (`_store_side`)."""
         eng = _engine()
         params = self._params_for_prep()
         rays = eng.upload_rays(self)
-        prep = eng.prepare(rays, params, bs_fov=self._data.get("bs_fov"), ue_fov=self._data.get("ue_fov"),
-                           ue_rotation_per_user=self._resolved_ue_rotation(), carrier_freq=self._carrier_freq(),
-                           want_side=want_side)
+        kw = dict(bs_fov=self._data.get("bs_fov"), ue_fov=self._data.get("ue_fov"),
+                  ue_rotation_per_user=self._resolved_ue_rotation(), carrier_freq=self._carrier_freq())
+        prep = eng.prepare(rays, params, want_side=want_side, **kw)
         if want_side:
-            self._store_side(prep)
+            self._store_side(prep, None if want_side is True else (rays, params.deepcopy(), kw))
         return eng, prep
 
-    def _store_side(self, prep) -> None:
+    def _store_side(self, prep, deferred=None) -> None:
         """Register every side product of stage 1 under the reference's cache keys.  The arrays stay in HBM
         (`_DeviceSide`) until something reads them: at 100k users x 25 paths they are ~120 MB of device-to-host
-        copies that a caller who only wants the channel tensor never pays for."""
-        s = prep.side
+        copies that a caller who only wants the channel tensor never pays for.  With `deferred` = (device rays, params,
+        prepare keywords) the rotated angles and powers are not even computed yet: the first read of any of them
+        re-runs stage 1 on the SAME uploaded rays (80 MB per 100k users x 25 paths stay in HBM until then) with the same
+        parameters, FoV and resolved rotations."""
         memo: Dict[str, np.ndarray] = {}
+        heavy: Dict[str, Any] = {}
+
+        def side(name):
+            if name in prep.side:
+                return prep.side[name]
+            if not heavy:                                 # second stage-1 pass, once, for all deferred products
+                heavy.update(_engine().prepare(deferred[0], deferred[1], want_side=True, **deferred[2]).side)
+            return heavy[name]
 
         def host(name):                                   # one D2H copy per product, shared by its dependants
             if name not in memo:
-                memo[name] = s[name].cpu().numpy()
+                memo[name] = side(name).cpu().numpy()
             return memo[name]
 
-        has_mask = s["fov_mask"] is not None
+        has_mask = prep.side["fov_mask"] is not None
         d = self._data
         d[c.FOV_MASK_PARAM_NAME] = _DeviceSide(lambda: host("fov_mask").astype(bool)) if has_mask else None
         for k_rot, k_fov, name in zip(_ROT_KEYS, _FOV_ANGLE_KEYS, ("aod_el_rot", "aod_az_rot", "aoa_el_rot", "aoa_az_rot")):
@@ -235,6 +247,35 @@ class Dataset(DotDict):
         d[c.NUM_PATHS_PARAM_NAME] = _DeviceSide(lambda: host("num_paths").astype(np.int64))
         d[c.LOS_PARAM_NAME] = _DeviceSide(lambda: host("los").astype(np.int64))
 
+    @staticmethod
+    def _guard_host_copy(nbytes: int) -> None:
+        """Refuse a device-to-host copy that cannot fit: at the headline shape the channel tensor is 1 MB per user
+        (105 GB per 100k users) and `.cpu()` of it would take the process down with the host's OOM killer."""
+        if not config.get("host_copy_guard", True):
+            return
+        avail = None
+        try:
+            with open("/proc/meminfo") as f:
+                for line in f:
+                    if line.startswith("MemAvailable:"):
+                        avail = int(line.split()[1]) * 1024
+                        break
+        except OSError:
+            pass
+        if avail is not None and nbytes > 0.9 * avail:
+            raise MemoryError(
+                f"the channel tensor is {nbytes / 1e9:.1f} GB but only {avail / 1e9:.1f} GB of host memory are available: "
+                "keep it on the GPU with dm.config('channel_output', 'torch'), or generate it in user chunks with "
+                "Dataset.iter_channels(params, chunk_users=...); dm.config('host_copy_guard', False) disables this check.")
+
+    def __getstate__(self):
+        """Pickling: side products still in HBM are copied out first (their placeholders are closures)."""
+        self._host_all()
+        return {"_data": self._data}
+
+    def __setstate__(self, state):
+        object.__setattr__(self, "_data", state["_data"])
+
     def compute_channels(self, params: Optional[ChannelGenParameters] = None):
         """dataset.py:224-268.  Returns complex64 [n_ue, M_rx, M_tx, K] (freq_domain) or
         [n_ue, M_rx, M_tx, num_paths]: a NumPy array by default, the HBM-resident torch tensor when
@@ -243,12 +284,17 @@ class Dataset(DotDict):
             params = ChannelGenParameters() if self._data.get(c.CH_PARAMS_PARAM_NAME) is None else self.ch_params
         self.set_channel_params(params)
         np.random.seed(1001)                                                   # dataset.py:250
-        eng, prep = self._run_prep(want_side=True)
+        to_host = config.get("channel_output", "numpy") != "torch"
+        if to_host:                                                            # before any GPU work is spent on it
+            ofdm_, n_ant = params[c.PARAMSET_OFDM], [int(np.prod(params[s_][c.PARAMSET_ANT_SHAPE])) for s_ in (c.PARAMSET_ANT_BS, c.PARAMSET_ANT_UE)]
+            last = len(np.atleast_1d(ofdm_[c.PARAMSET_OFDM_SC_SAMP])) if params[c.PARAMSET_FD_CH] else int(params[c.PARAMSET_NUM_PATHS])
+            self._guard_host_copy(8 * int(self.n_ue) * n_ant[0] * n_ant[1] * last)
+        eng, prep = self._run_prep(want_side="light")
         chan = eng.channels(prep, variant=int(config.get("fd_kernel_variant", 0)))
         ofdm = params[c.PARAMSET_OFDM]
         if params[c.PARAMSET_FD_CH]:
             self._warn_symbol_duration(eng.max_delay(prep), ofdm)
-        out = chan if config.get("channel_output", "numpy") == "torch" else chan.cpu().numpy()
+        out = chan.cpu().numpy() if to_host else chan
         self[c.CHANNEL_PARAM_NAME] = out
         return out
 
@@ -261,7 +307,7 @@ class Dataset(DotDict):
             params = ChannelGenParameters() if self._data.get(c.CH_PARAMS_PARAM_NAME) is None else self.ch_params
         self.set_channel_params(params)
         np.random.seed(1001)
-        eng, prep = self._run_prep(want_side=True)
+        eng, prep = self._run_prep(want_side="light")
         n = prep.n_ue
         variant = int(config.get("fd_kernel_variant", 0))
         for b in range(0, n, max(1, int(chunk_users))):
@@ -276,7 +322,7 @@ class Dataset(DotDict):
             params = ChannelGenParameters() if self._data.get(c.CH_PARAMS_PARAM_NAME) is None else self.ch_params
         self.set_channel_params(params)
         np.random.seed(1001)
-        eng, prep = self._run_prep(want_side=True)
+        eng, prep = self._run_prep(want_side="light")
         y = eng.channels(prep, tx_codebook=codebook)
         return y if config.get("channel_output", "numpy") == "torch" else y.cpu().numpy()
 
@@ -294,7 +340,7 @@ class Dataset(DotDict):
             params = ChannelGenParameters() if self._data.get(c.CH_PARAMS_PARAM_NAME) is None else self.ch_params
         self.set_channel_params(params)
         np.random.seed(1001)
-        eng, prep = self._run_prep(want_side=True)
+        eng, prep = self._run_prep(want_side="light")
         amp, _ = eng.beam_power(prep, codebook, want_best=False)
         amp = amp.cpu().numpy()
         self._data["beam_mean_amplitude"] = amp

@@ -160,8 +160,9 @@ class ChannelEngine:
 
     # ------------------------------------------------------------------ stage 1
     def prepare(self, rays: DeviceRays, params, bs_fov=None, ue_fov=None, ue_rotation_per_user=None,
-                carrier_freq: float = 0.0, want_side: bool = True) -> PrepResult:
-        """Run dmx_path_prep.  ue_rotation_per_user: optional [N, 3] degrees (numpy/torch)."""
+                carrier_freq: float = 0.0, want_side=True) -> PrepResult:
+        """Run dmx_path_prep.  ue_rotation_per_user: optional [N, 3] degrees (numpy/torch).  want_side: True = every
+        side product, "light" = LoS / path counts / FoV mask only, False = none."""
         dev = self.device
         n, L = rays.n_ue, rays.n_paths
         ofdm = params[c.PARAMSET_OFDM]
@@ -196,9 +197,13 @@ class ChannelEngine:
         side = {}
         s = nat.DmxSide()
         if want_side:
+            # "light": what is cheap beside the channel generation - LoS, path counts, the FoV mask when a FoV is set
+            # (stage 1 then needs the angles as numbers anyway).  True: also the four rotated-angle matrices and the
+            # powers (float64 arccos / atan2 per path: ~1 ms per 100k users x 25 paths, 120 MB of stores).
             side["fov_mask"] = torch.empty((n, L), dtype=torch.uint8, device=dev) if p.fov_enabled else None
             side["num_paths"] = torch.empty((n,), dtype=torch.int32, device=dev)
             side["los"] = torch.empty((n,), dtype=torch.int32, device=dev)
+        if want_side is True:
             for k in ("aod_el_rot", "aod_az_rot", "aoa_el_rot", "aoa_az_rot", "power_linear_ant_gain"):
                 side[k] = torch.empty((n, L), dtype=torch.float64, device=dev)
             side["power_linear"] = torch.empty((n, L), dtype=torch.float32, device=dev)

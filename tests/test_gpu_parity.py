@@ -306,6 +306,33 @@ def test_side_products_stay_in_hbm_until_read():
     assert "los" not in ds.keys() and "_fov_mask" not in ds.keys()
 
 
+def test_dataset_pickles_with_side_products_still_in_hbm():
+    """the `_DeviceSide` placeholders are closures - pickling copies them out first; deferred products
+    (rotated angles, powers: a second stage-1 pass on first read) come out identical to an eager read."""
+    import pickle
+    import deepmimo_amd as dm
+    from deepmimo_amd.dataset import _DeviceSide
+    from oracle import oracle_np as onp
+    rays = onp.synth_rays(40, 9, seed=33)
+    p = dm.ChannelGenParameters()
+    p.bs_antenna.rotation = np.array([10, 20, 30])
+    p.ue_antenna.rotation = np.array([[0, 30], [0, 20], [-45, 45]])          # random per-user range, drawn once
+    ds = dm.Dataset(dict(rays))
+    H = ds.compute_channels(p)
+    assert isinstance(ds._data["_aod_el_rot"], _DeviceSide) and isinstance(ds._data["power_linear"], _DeviceSide)
+    ds2 = pickle.loads(pickle.dumps(ds))
+    assert not any(isinstance(v, _DeviceSide) for v in ds2._data.values())
+    ref = onp.compute_channels(rays, onp.make_params(bs_antenna=dict(rotation=np.array([10, 20, 30])),
+                                                     ue_antenna=dict(rotation=ds["_ue_rotation_resolved"])))
+    np.testing.assert_array_equal(ds2.los, ref["los"])
+    np.testing.assert_array_equal(ds2.channel, H)
+    for k in ("_aod_el_rot", "_aoa_az_rot"):
+        ok = ~np.isnan(ref[k])
+        assert np.array_equal(np.isnan(ds2[k]), ~ok) and np.all(np.abs(ds2[k] - ref[k])[ok] <= 1e-11)
+    np.testing.assert_allclose(ds2.power_linear, ref["power_linear"], rtol=1e-6, equal_nan=True)
+    np.testing.assert_array_equal(ds["_aod_el_rot"], ds2["_aod_el_rot"])      # the original reads the same values later
+
+
 def test_macro_dataset_fan_out():
     import deepmimo_amd as dm
     from oracle import oracle_np as onp
@@ -461,7 +488,10 @@ def test_beam_codebook_projection(cfg):
 def test_beam_power_fused_reduction(cfg):
     """dmx_beam_power / Dataset.compute_beam_power: np.abs(F @ H).mean(axis=1).mean(axis=-1) -> dBm -> argmax
     (docs/manual.ipynb cells 105, 110, 112) without H or F @ H ever being written; against the oracle's H reduced in
-    float64.  Mean amplitudes rtol 1e-5; dBm within one rounding step; best beam exact except near-ties."""
+    float64.  Mean amplitudes: 1e-5 of the user's strongest beam (the contraction's error is relative to the user's peak,
+    as for the channel itself: a beam 60 dB down cannot be met to rtol 1e-5 of ITS value by any fp32 result), and rtol
+    1e-5 element-wise for every beam within 30 dB of the strongest; dBm within one rounding step; best beam exact except
+    near-ties."""
     import deepmimo_amd as dm
     from deepmimo_amd.dataset import _engine
     from oracle import oracle_np as onp
@@ -489,20 +519,23 @@ def test_beam_power_fused_reduction(cfg):
         assert amp.shape == (n, cfg["nb"]) and amp.dtype == np.float32 and pwr.dtype == np.float64
         np.testing.assert_array_equal(ds.los, ref["los"])
         has = ref["los"] != -1
-        assert has.sum() > 0 and (~has).sum() > 0
-        np.testing.assert_allclose(amp[has], want_amp[has], rtol=1e-5, atol=0)
+        assert has.sum() > 0
+        peak = want_amp[has].max(axis=1, keepdims=True)
+        assert np.all(np.abs(amp[has] - want_amp[has]) <= 1e-5 * peak)
+        strong = want_amp[has] >= peak * 10 ** (-30 / 20)
+        np.testing.assert_allclose(amp[has][strong], want_amp[has][strong], rtol=1e-5, atol=0)
         assert np.all(amp[~has] == 0)
-        # cells 105 / 110 / 112 on the reference amplitudes
+        # cells 105 / 110 / 112 on the reference amplitudes, in the notebook's float32 (channel is complex64)
         want_pwr = np.zeros((n, cfg["nb"])) * np.nan
-        want_pwr[has] = np.around(20 * np.log10(want_amp[has]) + 30, 1)
+        want_pwr[has] = np.around(20 * np.log10(want_amp[has].astype(np.float32)) + 30, 1)
         assert np.array_equal(np.isnan(pwr), np.isnan(want_pwr))
-        assert np.nanmax(np.abs(pwr - want_pwr)) <= 0.1 + 1e-9                  # a value on a rounding boundary may step
-        assert np.mean(pwr[has] == want_pwr[has]) > 0.98
+        assert np.nanmax(np.abs(pwr - want_pwr)) <= 0.1 + 1e-4                  # a value on a rounding boundary may step
+        assert np.mean(np.abs(pwr[has] - want_pwr[has]) < 1e-4) > 0.98
         want_best = np.argmax(want_pwr, axis=1).astype(float)
         want_best[~has] = np.nan
         assert np.array_equal(np.isnan(best), np.isnan(want_best))
         for u in np.nonzero(has & (best != want_best))[0]:                       # only (near-)ties may differ
-            assert abs(want_pwr[u, int(best[u])] - want_pwr[u, int(want_best[u])]) <= 0.1 + 1e-9
+            assert abs(want_pwr[u, int(best[u])] - want_pwr[u, int(want_best[u])]) <= 0.1 + 1e-4
         # the kernel's own argmax (first maximum of the un-rounded means)
         eng = _engine()
         prep = eng.prepare(eng.upload_rays(rays), p.validate(n))
@@ -762,7 +795,11 @@ def test_cache_plumbing_sequence_matches_reference():
     assert np.array_equal(z["ref_s2_channel"], z["ref_s3_channel"])
 
 
-def test_hip_graph_replay():
+@pytest.mark.parametrize("bs,ue,sel", [([8, 4], [2, 1], np.arange(0, 512, 8)),      # 64 rows: 18 KB of LDS
+                                       ([8, 8], [2, 2], np.arange(512)),            # headline shape: 256 rows, 74 KB of LDS ->
+                                                                                    # hipFuncSetAttribute + occupancy query run inside the capture
+                                       ([8, 1], [1, 1], np.arange(512))])           # default arrays: the folded kernel
+def test_hip_graph_replay(bs, ue, sel):
     """The C-ABI calls only enqueue kernels (no allocation, no sync): stage 1 + stage 2 captured in a HIP graph and
     replayed on new ray data give the same tensor as fresh eager calls."""
     import torch
@@ -771,8 +808,8 @@ def test_hip_graph_replay():
     from oracle import oracle_np as onp
     eng = ChannelEngine(0)
     p = dm.ChannelGenParameters()
-    p.bs_antenna.shape, p.ue_antenna.shape = np.array([8, 4]), np.array([2, 1])
-    p.ofdm.selected_subcarriers = np.arange(0, 512, 8)
+    p.bs_antenna.shape, p.ue_antenna.shape = np.array(bs), np.array(ue)
+    p.ofdm.selected_subcarriers = sel
     p.validate(64)
     a, b = onp.synth_rays(64, 10, seed=1), onp.synth_rays(64, 10, seed=2)
     rays = eng.upload_rays(a)
@@ -793,9 +830,10 @@ def test_hip_graph_replay():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(torch.view_as_real(out), torch.view_as_real(want_b))
-    assert np.array_equal(prep.side["los"].cpu().numpy(), onp.compute_channels(b, onp.make_params(
-        bs_antenna=dict(shape=[8, 4]), ue_antenna=dict(shape=[2, 1]),
-        ofdm=dict(selected_subcarriers=np.arange(0, 512, 8))))["los"])
+    ref_b = onp.compute_channels(b, onp.make_params(bs_antenna=dict(shape=bs), ue_antenna=dict(shape=ue),
+                                                   ofdm=dict(selected_subcarriers=sel)))
+    assert np.array_equal(prep.side["los"].cpu().numpy(), ref_b["los"])
+    assert_channel_close(out.cpu().numpy(), ref_b["channel"], what="graph replay vs oracle")
 
 
 def test_reference_patch_gpu_path():
@@ -867,3 +905,77 @@ def test_c_abi_demo_client_matches_python_host():
     assert got["energy"] == pytest.approx(energy, rel=1e-9)
     assert got["wsum"] == pytest.approx(wsum, rel=1e-6, abs=1e-9 * np.sqrt(energy))
     assert got["los_sum"] == int(ds.los.sum()) and got["num_paths_sum"] == int(ds.num_paths.sum())
+
+
+@pytest.mark.parametrize("variant", [0, 1, 4, 5, 9, 12])
+@pytest.mark.parametrize("bs,ue,K", [([9, 5], [1, 1], 24), ([8, 6], [1, 1], 40), ([3, 3], [1, 1], 33), ([8, 1], [1, 1], 100),
+                                    ([4, 3], [1, 1], 7)])
+def test_output_guard_regions_stay_untouched(bs, ue, K, variant):
+    """Stores of partial tiles are dropped by the buffer range check (row offsets past the block, masked lanes of a
+    partial subcarrier block): nothing may land outside the caller's tensor.  The output sits between two
+    sentinel-filled guard regions of one allocation; M = 45 / 48 / 9 / 8 / 12 rows, K not a multiple of 16."""
+    import torch
+    import deepmimo_amd as dm
+    from deepmimo_amd.engine import ChannelEngine
+    from oracle import oracle_np as onp
+    n, L = 37, 11
+    M = bs[0] * bs[1] * ue[0] * ue[1]
+    if variant == 9 and (bs[0] * bs[1] + ue[0] * ue[1] + K) * L * 8 > 156 * 1024:
+        pytest.skip("tables exceed the LDS of the small-output kernel")
+    rays = onp.synth_rays(n, L, seed=400 + K)
+    p = dm.ChannelGenParameters()
+    p.bs_antenna.shape, p.ue_antenna.shape = np.array(bs), np.array(ue)
+    p.num_paths = L
+    p.ofdm.selected_subcarriers = np.arange(3, 3 + K)
+    p.validate(n)
+    eng = ChannelEngine(0)
+    prep = eng.prepare(eng.upload_rays(rays), p, want_side=False)
+    guard, size = 1 << 16, n * M * K
+    sentinel = complex(-12345.5, 54321.25)
+    big = torch.full((guard + size + guard,), sentinel, dtype=torch.complex64, device="cuda")
+    out = big[guard:guard + size].view(n, ue[0] * ue[1], bs[0] * bs[1], K)
+    eng.channels(prep, out=out, variant=variant)
+    torch.cuda.synchronize()
+    assert bool((big[:guard] == sentinel).all()) and bool((big[guard + size:] == sentinel).all()), "write outside the output tensor"
+    ref = onp.compute_channels(rays, onp.make_params(bs_antenna=dict(shape=bs), ue_antenna=dict(shape=ue), num_paths=L,
+                                                     ofdm=dict(selected_subcarriers=np.arange(3, 3 + K))))
+    assert_channel_close(out.cpu().numpy(), ref["channel"], what=f"guarded output, variant {variant}")
+    # the same for a user sub-range written into the middle of the tensor: its neighbours stay as they are
+    big.fill_(sentinel)
+    eng.channels(prep, out=out[5:20], user_begin=5, user_count=15, variant=variant)
+    torch.cuda.synchronize()
+    assert bool((out[:5] == sentinel).all()) and bool((out[20:] == sentinel).all())
+    assert_channel_close(out[5:20].cpu().numpy(), ref["channel"][5:20], what="sub-range")
+
+
+@pytest.mark.parametrize("L,per_user", [(40, True), (25, False), (7, True)])
+def test_prepare_without_side_products_matches_oracle(L, per_user):
+    """eng.prepare(..., want_side=False) - what bench.py times - takes stage 1's branch that skips arccos / atan2
+    (array-response steps straight from the rotated direction).  Against the oracle with rotated BS and UE, NaN-padded
+    rows with holes, per-user rotation and more than 32 paths."""
+    import deepmimo_amd as dm
+    from deepmimo_amd.engine import ChannelEngine
+    from oracle import oracle_np as onp
+    n = 53
+    rays = onp.synth_rays(n, L, seed=900 + L)
+    rng = np.random.default_rng(L)
+    hole = rng.uniform(size=(n, L)) < 0.15
+    for k in onp.RAY_KEYS:
+        rays[k][hole] = np.nan
+    ue_rot = rng.uniform(-70, 70, (n, 3)) if per_user else np.array([25, -40, 110])
+    bs_rot = np.array([-15, 35, 200])
+    p = dm.ChannelGenParameters()
+    p.bs_antenna.shape, p.ue_antenna.shape = np.array([6, 3]), np.array([2, 2])
+    p.bs_antenna.rotation, p.ue_antenna.rotation = bs_rot, ue_rot
+    p.num_paths = L
+    p.ofdm.selected_subcarriers = np.arange(0, 512, 9)
+    p.validate(n)
+    op = onp.make_params(bs_antenna=dict(shape=[6, 3], rotation=bs_rot), ue_antenna=dict(shape=[2, 2], rotation=ue_rot),
+                         num_paths=L, ofdm=dict(selected_subcarriers=np.arange(0, 512, 9)))
+    ref = onp.compute_channels(rays, op)
+    eng = ChannelEngine(0)
+    dr = eng.upload_rays(rays)
+    lean = eng.channels(eng.prepare(dr, p, ue_rotation_per_user=ue_rot if per_user else None, want_side=False))
+    full = eng.channels(eng.prepare(dr, p, ue_rotation_per_user=ue_rot if per_user else None, want_side=True))
+    assert_channel_close(lean.cpu().numpy(), ref["channel"], what="want_side=False")
+    assert_channel_close(full.cpu().numpy(), ref["channel"], what="want_side=True")

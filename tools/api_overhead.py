@@ -30,6 +30,41 @@ def main():
     rays = onp.synth_rays(args.users, w["L"], seed=5, all_valid=True)
     p = bench.make_params(w)
     dm.config("channel_output", "torch")
+    dev = torch.device("cuda", 0)
+    # (1) the floor: the two C-ABI calls on resident rays (what bench.py times), wall clock incl. launch + final sync
+    from deepmimo_amd.engine import ChannelEngine
+    eng = ChannelEngine(0)
+    drays = {k: torch.from_numpy(v).to(dev) for k, v in rays.items()}
+    dr = eng.upload_rays(drays)
+    prep = eng.prepare(dr, p, want_side=False)
+    out = torch.empty(eng.channel_shape(prep), dtype=torch.complex64, device=dev)
+    eng.relaunch(prep, out)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(args.rounds):
+        t0 = time.perf_counter()
+        eng.relaunch(prep, out)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    floor = float(np.median(ts))
+    print(f"two C-ABI calls (dmx_path_prep + dmx_channels_fd), resident rays, no side products: median {floor:.2f} ms")
+    del out, prep
+    # (2) the public API on DEVICE-resident rays (what dm.load(..., device='cuda') hands over)
+    for label, touch in (("Dataset.compute_channels, device rays", False), ("... + los / num_paths read", True)):
+        ts = []
+        for _ in range(args.rounds + 1):
+            ds = dm.Dataset(dict(drays))
+            ds["rx_pos"] = np.zeros((args.users, 3), np.float32)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            H = ds.compute_channels(p)
+            if touch:
+                _ = ds.los, ds.num_paths
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+            del H, ds
+        ts = ts[1:]                                                   # first call: allocator warm-up
+        print(f"{label}: median {np.median(ts):.2f} ms  min {np.min(ts):.2f} ms  = floor + {np.median(ts) - floor:.2f} ms")
     for label, touch in (("compute_channels only", False), ("compute_channels + los/num_paths", True)):
         ts = []
         for _ in range(args.rounds):
