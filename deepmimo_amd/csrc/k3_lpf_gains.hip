@@ -12,6 +12,7 @@
 // the direct kernel k3_lpf_gains: one workgroup per (user, kept path), taps and the N roots of unity in
 // LDS, thread k walks d with an exact integer phase index (d*sc_k mod N).
 #include "dmx_common.h"
+#include <stdlib.h>
 
 namespace dmx {
 
@@ -139,6 +140,129 @@ __global__ __launch_bounds__(256) void k3_lpf_fft(WsView ws, LpfArgs a, int log2
     }
 }
 
+// ---- FFT form, one WAVE per path ----------------------------------------------------------------------
+// k3_lpf_fft above spends its time in 9 radix-2 stages of workgroup barriers and LDS round trips (1.9 ms per 20k users at
+// N = 512: as much as half the contraction).  Here one wave transforms one path on its own: Stockham autosort passes
+// of radix 8 (then one of radix 4 or 2 when log2 N is not a multiple of 3), each butterfly held in registers, two LDS
+// buffers per wave (ping-pong, natural order in and out - no bit reversal), twiddles from a table of the N roots of
+// unity built once per persistent workgroup, no workgroup barrier after that.  N = 512: 3 passes instead of 9 stages.
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 caddf(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csubf(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }          // a * (-j)
+
+template <int R> __device__ __forceinline__ void dft_small(float2 (&v)[R]);
+template <> __device__ __forceinline__ void dft_small<2>(float2 (&v)[2]) {
+    const float2 a = v[0], b = v[1];
+    v[0] = caddf(a, b); v[1] = csubf(a, b);
+}
+template <> __device__ __forceinline__ void dft_small<4>(float2 (&v)[4]) {
+    const float2 t0 = caddf(v[0], v[2]), t1 = csubf(v[0], v[2]), t2 = caddf(v[1], v[3]), t3 = mul_mi(csubf(v[1], v[3]));
+    v[0] = caddf(t0, t2); v[1] = caddf(t1, t3); v[2] = csubf(t0, t2); v[3] = csubf(t1, t3);
+}
+template <> __device__ __forceinline__ void dft_small<8>(float2 (&v)[8]) {
+    constexpr float H = 0.70710678118654752f;
+    float2 a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a[k] = caddf(v[k], v[k + 4]); b[k] = csubf(v[k], v[k + 4]); }
+    b[1] = make_float2((b[1].x + b[1].y) * H, (b[1].y - b[1].x) * H);          // * e^{-j pi/4}
+    b[2] = mul_mi(b[2]);                                                       // * e^{-j pi/2}
+    b[3] = make_float2((b[3].y - b[3].x) * H, -(b[3].x + b[3].y) * H);         // * e^{-j 3pi/4}
+    dft_small<4>(a);
+    dft_small<4>(b);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { v[2 * m] = a[m]; v[2 * m + 1] = b[m]; }
+}
+
+// element e of a transform buffer lives at e + e/16: the pad makes the stride-8 writes of the first pass (lane l writes
+// elements 8l + r: two banks for the whole wave without it) conflict-free and costs the other passes at most 2-way
+__device__ __forceinline__ int fpad(int e) { return e + (e >> 4); }
+
+// one Stockham pass of radix R over N points: src -> dst, Ns = product of the radices already done
+template <int R>
+__device__ __forceinline__ void fft_pass(const float2* src, float2* dst, const float2* W, int N, int log2n, int Ns, int log2ns, int lane) {
+    const int nb = N / R;
+    constexpr int LR = R == 8 ? 3 : (R == 4 ? 2 : 1);
+    const int tw_shift = log2n - log2ns - LR;                       // W_{Ns R}^{m} = W_N^{m << tw_shift}
+    for (int j = lane; j < nb; j += 64) {
+        const int k = j & (Ns - 1);
+        float2 v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = src[fpad(j + r * nb)];
+        if (Ns > 1) {
+#pragma unroll
+            for (int r = 1; r < R; ++r) v[r] = cmulf(v[r], W[(k * r) << tw_shift]);
+        }
+        dft_small<R>(v);
+        const int j0 = ((j - k) << LR) + k;
+#pragma unroll
+        for (int r = 0; r < R; ++r) dst[fpad(j0 + r * Ns)] = v[r];
+    }
+}
+
+__host__ __device__ inline size_t lpf_buf_elems(int N) { return (size_t)N + N / 16 + 1; }
+__host__ __device__ inline size_t lpf_wave_lds_bytes(int N) { return (size_t)N * 8 + 4 * 2 * lpf_buf_elems(N) * 8; }
+
+__global__ __launch_bounds__(256) void k3_lpf_fft_wave(WsView ws, LpfArgs a, int log2n, int64_t user_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int N = a.N;
+    float2* W = reinterpret_cast<float2*>(smem);                                 // [N] exp(-j 2pi m / N)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float2* bufA = W + N + (size_t)wave * 2 * lpf_buf_elems(N);                  // this wave's two transform buffers
+    float2* bufB = bufA + lpf_buf_elems(N);
+    for (int m = tid; m < N; m += 256) {
+        float s, c;
+        sincos_rev(frac_rev(-(double)m / (double)N), s, c);
+        W[m] = make_float2(c, s);
+    }
+    __syncthreads();
+    for (int64_t ul = blockIdx.x; ul < user_count; ul += gridDim.x) {
+        const int64_t u = a.user_begin + ul;
+        const int n_keep = ws.n_keep[u];
+        for (int l = wave; l < n_keep; l += 4) {
+            const size_t rec = (size_t)u * ws.P + l;
+            const double dn = (double)ws.dn[rec];
+            const float cr = ws.c_re[rec], ci = ws.c_im[rec];
+            // np.sinc(d - dn) = sin(pi (d - dn)) / (pi (d - dn)) with sin(pi (d - dn)) = -(-1)^d sin(pi dn)
+            const float s0 = (float)sinpi(dn);
+            const double dv = a.doppler ? (double)ws.dop_v[rec] : 0.0, da = a.doppler ? (double)ws.dop_a[rec] : 0.0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");               // the previous path's gather has read bufA/bufB
+            __builtin_amdgcn_wave_barrier();
+            for (int d = lane; d < N; d += 64) {
+                const double x = (double)d - dn;
+                const float sn = x == 0.0 ? 1.0f : ((d & 1) ? s0 : -s0) / (float)(LPF_PI * x);
+                float hr = cr * sn, hi = ci * sn;
+                if (a.doppler) {
+                    const double tau = a.ts * (double)d;
+                    const double rev = -a.fc * (dv * tau / LPF_C0 + da * (tau * tau) / (2.0 * LPF_C0));
+                    float s, c;
+                    sincos_rev(frac_rev(rev), s, c);
+                    const float nr = hr * c - hi * s, ni = hr * s + hi * c;
+                    hr = nr; hi = ni;
+                }
+                bufA[fpad(d)] = make_float2(hr, hi);
+            }
+            float2* src = bufA;
+            float2* dst = bufB;
+            int log2ns = 0;
+            while (log2ns < log2n) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                const int left = log2n - log2ns;
+                if (left >= 3) { fft_pass<8>(src, dst, W, N, log2n, 1 << log2ns, log2ns, lane); log2ns += 3; }
+                else if (left == 2) { fft_pass<4>(src, dst, W, N, log2n, 1 << log2ns, log2ns, lane); log2ns += 2; }
+                else { fft_pass<2>(src, dst, W, N, log2n, 1 << log2ns, log2ns, lane); log2ns += 1; }
+                float2* t = src; src = dst; dst = t;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            float2* grow = a.gtab + ((size_t)ul * ws.P + l) * a.K;
+            for (int k = lane; k < a.K; k += 64) grow[k] = src[fpad(a.sc[k] & (N - 1))];   // N is a power of two: floor-mod
+        }
+    }
+}
+
 int launch_channels_fd_lpf_contract(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
                                     const float2* gtab, float2* out, hipStream_t stream);
 
@@ -151,9 +275,26 @@ int launch_channels_fd_lpf(const dmx_params& prm, const WsView& ws, int64_t user
         a.gtab = gtab; a.doppler = prm.enable_doppler; a.fc = prm.carrier_freq; a.ts = 1.0 / prm.bandwidth;
         if ((size_t)a.N * 16 > 64 * 1024) { set_error("rx_filter variant supports at most 4096 subcarriers (got %d)", a.N); return DMX_ERR_SHAPE; }
         const bool pow2 = a.N >= 2 && (a.N & (a.N - 1)) == 0;
-        if (pow2) {
-            int log2n = 0;
-            while ((1 << log2n) < a.N) ++log2n;
+        int log2n = 0;
+        while ((1 << log2n) < a.N) ++log2n;
+        const char* old = getenv("DMX_LPF_OLD_FFT");                  // measurement hook: the workgroup-per-user FFT
+        if (pow2 && a.N >= 64 && a.N <= 2048 && !(old && old[0] == '1')) {
+            // wave-per-path radix-8 FFT; persistent workgroups (the twiddle table is built once per workgroup)
+            const size_t smem = lpf_wave_lds_bytes(a.N);
+            const void* kfn = reinterpret_cast<const void*>(k3_lpf_fft_wave);
+            if (smem > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
+            }
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, smem) != hipSuccess || per_cu < 1) {
+                (void)hipGetLastError();
+                per_cu = 1;
+            }
+            int64_t grid = (int64_t)device_cu_count() * per_cu;
+            if (grid > user_count) grid = user_count;
+            hipLaunchKernelGGL(k3_lpf_fft_wave, dim3((unsigned)grid), dim3(256), smem, stream, ws, a, log2n, user_count);
+        } else if (pow2) {
             // paths transformed together: every stage costs one workgroup barrier whatever PB is, so batch as
             // many paths as 32 KiB of LDS hold (8 at N = 512) - 25 paths then need 4 x 9 barriers instead of 25 x 9
             int PB = 4096 / a.N;

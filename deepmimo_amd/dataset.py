@@ -82,7 +82,7 @@ class Dataset(DotDict):
             self._host(k)
 
     def __getattr__(self, key: str) -> Any:
-        if key.startswith("__"):
+        if key == "_data" or key.startswith("__"):
             raise AttributeError(key)
         try:
             return self._host(key)

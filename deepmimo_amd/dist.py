@@ -181,7 +181,8 @@ def compute_channels_sharded(data, params, bs_fov=None, ue_fov=None, group=None,
     rank, world = _world(group)
     if device_index is None:
         device_index = torch.cuda.current_device()
-    children = data.datasets if hasattr(data, "datasets") else (list(data) if isinstance(data, (list, tuple)) else None)
+    from .dataset import MacroDataset
+    children = data.datasets if isinstance(data, MacroDataset) else (list(data) if isinstance(data, (list, tuple)) else None)
     if children is not None:
         n_users = [int(d[c.POWER_PARAM_NAME].shape[0]) for d in children]
         return {i: compute_channels_sharded(children[i], params, bs_fov=bs_fov, ue_fov=ue_fov, group=group,

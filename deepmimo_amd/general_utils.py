@@ -24,10 +24,18 @@ class DotDict(Mapping):
 
     # attribute protocol ------------------------------------------------------------
     def __getattr__(self, key: str) -> Any:
+        if key == "_data" or key.startswith("__"):       # an instance pickle has created but not yet filled, protocol probes
+            raise AttributeError(key)
         try:
             return self._data[key]
         except KeyError:
             raise AttributeError(key) from None
+
+    def __getstate__(self):
+        return {"_data": self._data}
+
+    def __setstate__(self, state):
+        object.__setattr__(self, "_data", state["_data"])
 
     def __setattr__(self, key: str, value: Any) -> None:
         if key == "_data":

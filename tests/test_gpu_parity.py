@@ -873,7 +873,7 @@ def test_c_abi_demo_client_matches_python_host():
     r = subprocess.run([exe, str(n)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     got = json.loads(r.stdout.strip().splitlines()[-1])
-    assert got["abi"] == 1 and got["shape"] == [n, 2, 16, K]
+    assert got["abi"] == 2 and got["shape"] == [n, 2, 16, K]
     # the demo's LCG, vectorised: s_{i+1} = a s_i + c (mod 2^32)
     total = 8 * n * L
     state = np.empty(total, dtype=np.uint64)
