@@ -289,8 +289,8 @@ bool fd_fold_preferred(const dmx_params& prm, const WsView& ws);
 // what variant 0 runs for this shape: 9 small-output kernel, 12 folded matrix-core kernel (few antenna pairs, uniformly
 // spaced subcarriers), 2 matrix cores, 1 fp32 vector kernel
 int fd_auto_choice(const dmx_params& prm, const WsView& ws) {
-    if (fd_small_preferred(prm, ws)) return 9;
     if (fd_fold_preferred(prm, ws)) return 12;
+    if (fd_small_preferred(prm, ws)) return 9;
     if (fd_mfma_preferred(prm, ws)) return 2;
     return 1;
 }
@@ -316,12 +316,16 @@ int launch_channels_fd(const dmx_params& prm, const WsView& ws, int64_t user_beg
 }
 
 int launch_channels_fd_mfma_gload(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
-                                  const float2* gtab, float2* out, hipStream_t stream);
+                                  const float2* gtab, float2* out, hipStream_t stream, bool packed);
+
+// the gains table may be written in the packed f16 form when the matrix-core kernel is its only reader (at most 32 path
+// slots: further slots go through the fp32 vector kernel's accumulate passes, which read floats)
+bool lpf_table_packed(const dmx_params& prm, const WsView& ws) { return fd_mfma_preferred(prm, ws) && ws.P <= 32; }
 
 int launch_channels_fd_lpf_contract(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
-                                    const float2* gtab, float2* out, hipStream_t stream) {
+                                    const float2* gtab, float2* out, hipStream_t stream, bool packed) {
     int rc;
-    if (fd_mfma_preferred(prm, ws)) rc = launch_channels_fd_mfma_gload(prm, ws, user_begin, user_count, gtab, out, stream);
+    if (fd_mfma_preferred(prm, ws)) rc = launch_channels_fd_mfma_gload(prm, ws, user_begin, user_count, gtab, out, stream, packed);
     else rc = launch_fd_valu_any(prm, ws, user_begin, user_count, gtab, out, stream);
     return rc ? rc : launch_extra_path_passes(prm, ws, user_begin, user_count, gtab, out, stream);
 }

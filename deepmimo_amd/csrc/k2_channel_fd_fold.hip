@@ -296,10 +296,21 @@ static int fold_chunk_blocks(int M, int nblk, int forced) {
     return best < nblk ? best : nblk;
 }
 
-// Automatic choice (variant 0): up to 32 pairs from 32 subcarriers on.  TODO(sweep): crossovers from tools/fold_sweep.sh
+// Automatic choice (variant 0), from profiles/r2_fold_sweep.txt (200k users x 25 paths; ms for this kernel | the best of
+// the others: 9 small-output, 2 matrix cores, 1 fp32 vector):
+//    8 pairs: K=4 0.17 | 0.19 (9)   K=8 0.20 | 0.30 (9)   K=16 0.24 | 0.52 (9)   K=64 0.28 | 1.31 (1)   K=512 1.35 | 6.6 (2)
+//   32 pairs: K=8 0.35 | 0.47 (9)   K=16 0.41 | 1.16 (9)   K=64 0.76 | 2.29 (2)   K=256 2.79 | 5.2 (2)   K=512 5.7 | 7.9 (2)
+//   48 pairs: K=64 1.40 | 2.60 (2)  K=128 2.23 | 3.57 (2)  K=256 5.17 | 6.40 (2)  K=512 10.2 | 10.1 (2)
+//   64 pairs: K=8 0.76 | 1.07 (9)   K=32 1.08 | 2.24 (2)   K=64 1.57 | 2.83 (2)   K=128 3.85 | 4.14 (2)  K=256 7.97 | 7.19 (2)
+// Beyond 32 pairs the per-wave tables (Ac: 272 B per pair) cut the resident workgroups and the plain matrix-core kernel,
+// whose B' generation is then shared by two or more full row tiles, catches up from the many-subcarrier end.
 bool fd_fold_preferred(const dmx_params& prm, const WsView& ws) {
     const int64_t M = (int64_t)prm.ue_shape[0] * prm.ue_shape[1] * prm.bs_shape[0] * prm.bs_shape[1];
-    return fd_fold_supported(prm, ws) && M <= 32 && prm.n_selected >= 32;
+    const int K = prm.n_selected;
+    if (!fd_fold_supported(prm, ws) || K < 4) return false;
+    if (M <= 32) return true;
+    if (M <= 48) return K <= 256;
+    return K <= 128;
 }
 
 int launch_channels_fd_fold(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count, float2* out,

@@ -47,6 +47,7 @@ struct MfmaArgs {
     const int32_t* fexp;     // [user_count]              exponent of max |f| per user
     // rx_filter variant: per-path subcarrier gains precomputed by k3_lpf_* instead of generated here
     const float2* gtab;      // [user_count, P, K] or nullptr
+    const uint2* gpack;      // the same table in packed f16 hi/lo form (load_b_step_packed) or nullptr
 };
 
 // One 32-row tile of one strip: 2*NS ds_read_b128 of A' issued together, 3*NS MFMAs, 16 stores.  NS = K-steps that
@@ -279,7 +280,7 @@ __device__ __forceinline__ void stage_item(const WsView& ws, const MfmaArgs& a, 
         // scaled per user so that max |f| lands in [32, 64)
         const int ea = a.n_beams ? 6 - a.fexp[ip.ul] : 6;
         // rx_filter: |G| can exceed |c| by the sinc sum (a few x); two bits of headroom keep G*gs < 2^13
-        if (a.gtab) e += 2;
+        if (a.gtab || a.gpack) e += 2;
         if (lane == 0) { L.misc[0] = ldexpf(1.0f, e - 10 - ea); L.misc[1] = ldexpf(1.0f, ea); L.misc[2] = ldexpf(1.0f, 10 - e); }
     }
 
@@ -327,7 +328,9 @@ __device__ __forceinline__ void stage_item(const WsView& ws, const MfmaArgs& a, 
 // Stage 2 of a work item, after a barrier behind stage_item: a wave owns one 32-column strip at a time (B'
 // fragments in registers) and walks the row tiles with it, so the waves of the workgroup fill one 32-row band of the
 // user's block together and their stores stay within a few DRAM pages.  No barrier inside.
-template <bool NT, int NW, int MODE>
+// GSRC: where the subcarrier gains G[l,k] come from - 0 generated here (plain path), 1 float table, 2 packed f16 table
+// (rx_filter path).  A template parameter: the plain kernel carries none of the table code.
+template <bool NT, int NW, int MODE, int GSRC>
 __device__ __forceinline__ void consume_item(const WsView& ws, const MfmaArgs& a, float* __restrict__ out, int64_t work,
                                              const ItemLds& L) {
     constexpr int NTHR = NW * 64;
@@ -343,7 +346,8 @@ __device__ __forceinline__ void consume_item(const WsView& ws, const MfmaArgs& a
     }
     const float oscale = L.misc[0];
     const float gscale = L.misc[2];
-    const float2* grow = a.gtab ? a.gtab + (size_t)ip.ul * ws.P * a.K : nullptr;
+    const float2* grow = GSRC == 1 ? a.gtab + (size_t)ip.ul * ws.P * a.K : nullptr;
+    const uint2* prow = GSRC == 2 ? a.gpack + (size_t)ip.ul * ws.P * a.K : nullptr;
 
     const int col = lane & 31, hh = lane >> 5;
     const unsigned row_bytes = (unsigned)twoK * 4u;
@@ -354,7 +358,10 @@ __device__ __forceinline__ void consume_item(const WsView& ws, const MfmaArgs& a
         const BLane bl = b_lane(strip, col, hh, twoK, a.sc);
         h8 Bhi[4], Blo[4];
 #pragma unroll
-        for (int st = 0; st < 4; ++st) gen_b_step(st, bl, hh, n_act, L.qtab, L.crtab, L.citab, grow, a.K, gscale, Bhi[st], Blo[st]);
+        for (int st = 0; st < 4; ++st) {
+            if constexpr (GSRC == 2) load_b_step_packed(st, bl, hh, n_act, prow, a.K, Bhi[st], Blo[st]);
+            else gen_b_step(st, bl, hh, n_act, L.qtab, L.crtab, L.citab, grow, a.K, gscale, Bhi[st], Blo[st]);
+        }
         if constexpr (MODE != 0) {
             constexpr bool PIPE = MODE == 2;
             switch ((n_act + 7) >> 3) {                                   // workgroup-uniform
@@ -372,14 +379,14 @@ __device__ __forceinline__ void consume_item(const WsView& ws, const MfmaArgs& a
 
 // One (user, row block) per loop iteration.  Launched with one workgroup per work item, or persistently (grid =
 // what is resident at once, workgroups stride over the work items).
-template <bool NT, int NW, int MODE>
+template <bool NT, int NW, int MODE, int GSRC>
 __global__ __launch_bounds__(NW * 64, 4) void k2_fd_mfma(WsView ws, MfmaArgs a, float* __restrict__ out, int64_t total) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ItemLds L = item_lds(smem, a.rows);
     for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
         stage_item<NW>(ws, a, w, L);
         __syncthreads();
-        consume_item<NT, NW, MODE>(ws, a, out, w, L);
+        consume_item<NT, NW, MODE, GSRC>(ws, a, out, w, L);
         __syncthreads();                                                 // the next item's tiles overwrite these
     }
 }
@@ -604,17 +611,17 @@ static int64_t resident_grid(const void* kfn, int threads, size_t smem, int64_t 
     return blocks < grid ? blocks : grid;
 }
 
-template <bool NT, int NW, int MODE = 0>
+template <bool NT, int NW, int MODE = 0, int GSRC = 0>
 static int launch_mfma_t(const WsView& ws, const MfmaArgs& a, int64_t blocks, size_t smem, float2* out, hipStream_t stream,
                          bool persistent = true, int items_per_wg = ITEMS_PER_WG) {
-    const void* kfn = reinterpret_cast<const void*>(k2_fd_mfma<NT, NW, MODE>);
+    const void* kfn = reinterpret_cast<const void*>(k2_fd_mfma<NT, NW, MODE, GSRC>);
     if (smem > 64 * 1024) {     // per device and cheap: no cached flag, so every GPU of a process gets it
         hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, MFMA_LDS_MAX);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
     }
     int64_t grid = blocks;
     if (persistent) grid = resident_grid(kfn, NW * 64, smem, blocks, items_per_wg);
-    hipLaunchKernelGGL((k2_fd_mfma<NT, NW, MODE>), dim3((unsigned)grid), dim3(NW * 64), smem, stream, ws, a, reinterpret_cast<float*>(out), blocks);
+    hipLaunchKernelGGL((k2_fd_mfma<NT, NW, MODE, GSRC>), dim3((unsigned)grid), dim3(NW * 64), smem, stream, ws, a, reinterpret_cast<float*>(out), blocks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("k2_fd_mfma launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
     return DMX_OK;
@@ -622,10 +629,13 @@ static int launch_mfma_t(const WsView& ws, const MfmaArgs& a, int64_t blocks, si
 
 static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
                            float2* out, int config, int n_beams, const float2* ftab, const int32_t* fexp,
-                           const float2* gtab, hipStream_t stream);
+                           const float2* gtab, hipStream_t stream, const uint2* gpack = nullptr);
 
 int launch_channels_fd_mfma_gload(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
-                                  const float2* gtab, float2* out, hipStream_t stream) {
+                                  const float2* gtab, float2* out, hipStream_t stream, bool packed) {
+    if (packed)
+        return launch_mfma_any(prm, ws, user_begin, user_count, out, 0, 0, nullptr, nullptr, nullptr, stream,
+                               reinterpret_cast<const uint2*>(gtab));
     return launch_mfma_any(prm, ws, user_begin, user_count, out, 0, 0, nullptr, nullptr, gtab, stream);
 }
 
@@ -685,9 +695,9 @@ int launch_channels_fd_beams(const dmx_params& prm, const WsView& ws, int64_t us
 
 static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
                            float2* out, int config, int n_beams, const float2* ftab, const int32_t* fexp,
-                           const float2* gtab, hipStream_t stream) {
+                           const float2* gtab, hipStream_t stream, const uint2* gpack) {
     MfmaArgs a;
-    a.n_beams = n_beams; a.ftab = ftab; a.fexp = fexp; a.gtab = gtab;
+    a.n_beams = n_beams; a.ftab = ftab; a.fexp = fexp; a.gtab = gtab; a.gpack = gpack;
     a.user_begin = user_begin;
     a.m_rx = prm.ue_shape[0] * prm.ue_shape[1];
     a.m_tx = prm.bs_shape[0] * prm.bs_shape[1];
@@ -727,6 +737,19 @@ static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user
         if (ws.P <= 16) return launch_mfma_t<true, 8, 1>(ws, a, blocks, smem, out, stream, persistent, items_per_wg);
         return launch_mfma_t<true, 8, 2>(ws, a, blocks, smem, out, stream, persistent, items_per_wg);
     };
+    if (gtab || gpack) {                                   // rx_filter path: gains from the table (float or packed f16)
+        const bool small = nstrips <= 8 && a.rows < 128;
+        if (gpack) {
+            if (small) return launch_mfma_t<true, 4, 0, 2>(ws, a, blocks, smem, out, stream, true, 0);
+            if (a.rows < 128) return launch_mfma_t<true, 8, 0, 2>(ws, a, blocks, smem, out, stream, true, ITEMS_PER_WG8);
+            if (ws.P <= 16) return launch_mfma_t<true, 8, 1, 2>(ws, a, blocks, smem, out, stream, true, ITEMS_PER_WG8);
+            return launch_mfma_t<true, 8, 2, 2>(ws, a, blocks, smem, out, stream, true, ITEMS_PER_WG8);
+        }
+        if (small) return launch_mfma_t<true, 4, 0, 1>(ws, a, blocks, smem, out, stream, true, 0);
+        if (a.rows < 128) return launch_mfma_t<true, 8, 0, 1>(ws, a, blocks, smem, out, stream, true, ITEMS_PER_WG8);
+        if (ws.P <= 16) return launch_mfma_t<true, 8, 1, 1>(ws, a, blocks, smem, out, stream, true, ITEMS_PER_WG8);
+        return launch_mfma_t<true, 8, 2, 1>(ws, a, blocks, smem, out, stream, true, ITEMS_PER_WG8);
+    }
     switch (config) {
         case 1: return launch_mfma_t<false, 16>(ws, a, blocks, smem, out, stream);   // plain stores
         case 2: return launch_mfma_t<true, 4>(ws, a, blocks, smem, out, stream);

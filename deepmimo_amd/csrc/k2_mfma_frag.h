@@ -95,6 +95,33 @@ __device__ __forceinline__ void gen_b_step(int s, const BLane& bl, int hh, int n
     }
 }
 
+// One K-step of the strip's B' fragments from the PACKED gains table the rx_filter path's FFT kernel writes
+// (k3_lpf_fft_wave, pack = 1): entry (l, k) is {f16 pair (re, im) of hi, f16 pair (re, im) of lo} of G[l,k] already scaled
+// by the user's power of two - no scaling, no split, no lane-pair exchange here: a column c = 0 lane wants
+// (Re, -Im) = the pair with the upper sign bit flipped, a c = 1 lane wants (Im, Re) = the pair rotated by 16 bits.
+__device__ __forceinline__ void load_b_step_packed(int s, const BLane& bl, int hh, int n_act, const uint2* __restrict__ prow, int K,
+                                                   h8& Bhi, h8& Blo) {
+    Bhi = h8{0, 0, 0, 0, 0, 0, 0, 0};
+    Blo = Bhi;
+    if (8 * s >= n_act) return;
+    const unsigned rot = bl.c ? 16u : 0u, sgn = bl.c ? 0u : 0x80000000u;
+    uint2 g[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int pl = 8 * s + 4 * hh + jj;
+        g[jj] = make_uint2(0u, 0u);
+        if (bl.kok && pl < n_act) g[jj] = prow[(size_t)pl * K + bl.kidx];
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const unsigned xh = __builtin_amdgcn_alignbit(g[jj].x, g[jj].x, rot) ^ sgn;
+        const unsigned xl = __builtin_amdgcn_alignbit(g[jj].y, g[jj].y, rot) ^ sgn;
+        const h2 ph = __builtin_bit_cast(h2, xh), pl2 = __builtin_bit_cast(h2, xl);
+        Bhi[2 * jj] = ph[0]; Bhi[2 * jj + 1] = ph[1];
+        Blo[2 * jj] = pl2[0]; Blo[2 * jj + 1] = pl2[1];
+    }
+}
+
 // k2b_beam_project's output inside the beam workspace
 struct BeamTabs {
     const float2* ftab;      // [user_count, n_beams, P]  f[b,l] = sum_tx F[b,tx] a_tx[tx,l]

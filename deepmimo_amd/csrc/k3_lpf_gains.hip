@@ -11,7 +11,7 @@
 // N = K = 512 that is 57x less work and the variant costs about as much as the plain path).  Other N use
 // the direct kernel k3_lpf_gains: one workgroup per (user, kept path), taps and the N roots of unity in
 // LDS, thread k walks d with an exact integer phase index (d*sc_k mod N).
-#include "dmx_common.h"
+#include "k2_mfma_frag.h"
 #include <stdlib.h>
 
 namespace dmx {
@@ -23,6 +23,7 @@ struct LpfArgs {
     float2* gtab;
     int doppler;
     double fc, ts;
+    int pack;          // k3_lpf_fft_wave only: write {f16 hi (re, im), f16 lo (re, im)} of G scaled by the user's power of two
 };
 
 static constexpr double LPF_PI = 3.141592653589793;
@@ -220,6 +221,17 @@ __global__ __launch_bounds__(256) void k3_lpf_fft_wave(WsView ws, LpfArgs a, int
     for (int64_t ul = blockIdx.x; ul < user_count; ul += gridDim.x) {
         const int64_t u = a.user_begin + ul;
         const int n_keep = ws.n_keep[u];
+        float gsl = 1.0f;
+        if (a.pack) {
+            // the operand scale k2_fd_mfma's stage_item derives for this user: max |c| component -> [512, 1024), two
+            // more bits of headroom for the sinc sum
+            float m = 0.f;
+            if (lane < (n_keep < 32 ? n_keep : 32)) m = fmaxf(fabsf(ws.c_re[(size_t)u * ws.P + lane]), fabsf(ws.c_im[(size_t)u * ws.P + lane]));
+            for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+            int e;
+            (void)frexpf(m, &e);
+            gsl = ldexpf(1.0f, 8 - e);
+        }
         for (int l = wave; l < n_keep; l += 4) {
             const size_t rec = (size_t)u * ws.P + l;
             const double dn = (double)ws.dn[rec];
@@ -258,27 +270,42 @@ __global__ __launch_bounds__(256) void k3_lpf_fft_wave(WsView ws, LpfArgs a, int
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
             float2* grow = a.gtab + ((size_t)ul * ws.P + l) * a.K;
-            for (int k = lane; k < a.K; k += 64) grow[k] = src[fpad(a.sc[k] & (N - 1))];   // N is a power of two: floor-mod
+            if (a.pack) {
+                uint2* prow = reinterpret_cast<uint2*>(grow);
+                for (int k = lane; k < a.K; k += 64) {
+                    const float2 g = src[fpad(a.sc[k] & (N - 1))];
+                    h2 hi, lo;
+                    split2_f16(g.x * gsl, g.y * gsl, hi, lo);
+                    prow[k] = make_uint2(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo));
+                }
+            } else {
+                for (int k = lane; k < a.K; k += 64) grow[k] = src[fpad(a.sc[k] & (N - 1))];   // N is a power of two: floor-mod
+            }
         }
     }
 }
 
 int launch_channels_fd_lpf_contract(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
-                                    const float2* gtab, float2* out, hipStream_t stream);
+                                    const float2* gtab, float2* out, hipStream_t stream, bool packed);
+bool lpf_table_packed(const dmx_params& prm, const WsView& ws);
 
 int launch_channels_fd_lpf(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
                            float2* gtab, float2* out, hipStream_t stream) {
     if (user_count == 0 || prm.n_selected == 0) return DMX_OK;
+    bool packed = false;
     if (ws.P > 0) {
         LpfArgs a;
         a.user_begin = user_begin; a.N = prm.n_subcarriers; a.K = prm.n_selected; a.sc = prm.selected_subcarriers;
         a.gtab = gtab; a.doppler = prm.enable_doppler; a.fc = prm.carrier_freq; a.ts = 1.0 / prm.bandwidth;
+        a.pack = 0;
         if ((size_t)a.N * 16 > 64 * 1024) { set_error("rx_filter variant supports at most 4096 subcarriers (got %d)", a.N); return DMX_ERR_SHAPE; }
         const bool pow2 = a.N >= 2 && (a.N & (a.N - 1)) == 0;
         int log2n = 0;
         while ((1 << log2n) < a.N) ++log2n;
         const char* old = getenv("DMX_LPF_OLD_FFT");                  // measurement hook: the workgroup-per-user FFT
         if (pow2 && a.N >= 64 && a.N <= 2048 && !(old && old[0] == '1')) {
+            const char* nopack = getenv("DMX_LPF_FLOAT_TABLE");        // measurement hook: keep the float table
+            a.pack = packed = lpf_table_packed(prm, ws) && !(nopack && nopack[0] == '1');
             // wave-per-path radix-8 FFT; persistent workgroups (the twiddle table is built once per workgroup)
             const size_t smem = lpf_wave_lds_bytes(a.N);
             const void* kfn = reinterpret_cast<const void*>(k3_lpf_fft_wave);
@@ -311,7 +338,7 @@ int launch_channels_fd_lpf(const dmx_params& prm, const WsView& ws, int64_t user
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { set_error("k3 lpf gains launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
     }
-    return launch_channels_fd_lpf_contract(prm, ws, user_begin, user_count, gtab, out, stream);
+    return launch_channels_fd_lpf_contract(prm, ws, user_begin, user_count, gtab, out, stream, packed);
 }
 
 }  // namespace dmx

@@ -59,6 +59,9 @@ int main(int argc, char** argv) {
     prm.bs_rotation[2] = 30.0 * M_PI / 180.0;                 // radians, as np.deg2rad gives them
     prm.num_paths = 25; prm.freq_domain = 1; prm.n_subcarriers = 512; prm.n_selected = K;
     prm.selected_subcarriers = d_sc; prm.bandwidth = 10e6;
+    // host-side promise about d_sc (ABI 2): sc[k] = sc_first + k * sc_stride.  It lets variant 0 take the folded
+    // matrix-core kernel for this 32-pair panel; leave sc_stride = 0 for an arbitrary selection.
+    prm.sc_first = 0; prm.sc_stride = 1;
 
     void *ws, *out;
     int32_t *d_los, *d_np;

@@ -9,7 +9,10 @@ import sys
 
 def main():
     tag, stats, pmcs = sys.argv[1], sys.argv[2], sys.argv[3:]
-    out = [f"# rocprofv3 summary '{tag}' (python3 bench.py, headline config: 100000 users x 64x4 ant x 25 paths x 512 sc)",
+    what = "headline config: 100000 users x 64x4 ant x 25 paths x 512 sc"
+    if pmcs and not pmcs[0].endswith(".csv"):                      # optional description of the profiled bench command
+        what, pmcs = pmcs[0], pmcs[1:]
+    out = [f"# rocprofv3 summary '{tag}' (python3 bench.py, {what})",
            "", "## --kernel-trace --stats (dmx kernels)", "name,calls,avg_ns,min_ns,max_ns,pct"]
     for r in csv.DictReader(open(stats)):
         if "dmx::" in r["Name"]:
