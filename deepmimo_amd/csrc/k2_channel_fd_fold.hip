@@ -307,7 +307,9 @@ static int fold_chunk_blocks(int M, int nblk, int forced) {
 bool fd_fold_preferred(const dmx_params& prm, const WsView& ws) {
     const int64_t M = (int64_t)prm.ue_shape[0] * prm.ue_shape[1] * prm.bs_shape[0] * prm.bs_shape[1];
     const int K = prm.n_selected;
-    if (!fd_fold_supported(prm, ws) || K < 4) return false;
+    // below one 16-subcarrier block this kernel's time is flat in K while the small-output kernel's grows with M*K:
+    // 8 pairs K=1 0.15 | 0.12 (9), K=3 0.175 | 0.170, K=4 0.17 | 0.19; 64 pairs K=1 0.64 | 0.18, K=4 0.69 | 0.54, K=8 0.76 | 1.07
+    if (!fd_fold_supported(prm, ws) || K < (M <= 16 ? 4 : 6)) return false;
     if (M <= 32) return true;
     if (M <= 48) return K <= 256;
     return K <= 128;

@@ -16,11 +16,18 @@ static constexpr int LPAD = 32;              // path slots (kk = 64)
 static constexpr float A_SCALE = 64.0f;      // 2^6
 
 // (x0, x1) -> packed hi pair and packed lo pair, x = hi + lo.  v_cvt_pkrtz_f16_f32 converts two floats per
-// instruction; with round-toward-zero x - hi is exact in fp32 and lo keeps 11 more bits of it.
+// instruction; with round-toward-zero x - hi is exact in fp32 and lo keeps 11 more bits of it.  The residual is ONE
+// v_fma_mix_f32 per value (it reads the f16 half of the packed register directly: op_sel_hi marks the operand as f16,
+// op_sel picks the half); the compiler's own form is v_cvt_f32_f16 + v_sub_f32.  Same-box A/B at the headline shape
+// (tools/ab_two_libs.sh): 15.80 vs 16.21 ms.
 typedef __fp16 hp2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2_f16(float x0, float x1, h2& hi, h2& lo) {
     const hp2 h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-    const hp2 l = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
+    const unsigned hb = __builtin_bit_cast(unsigned, h);
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hb), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "v"(x1));
+    const hp2 l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
     hi = __builtin_bit_cast(h2, h);
     lo = __builtin_bit_cast(h2, l);
 }
