@@ -29,6 +29,7 @@
 //            a scalar offset of the buffer instruction, so the epilogue is 1 VALU op per store.
 // HBM traffic = the 8*M*K output bytes (written once) + ~1 KB of path records per user.
 #include "k2_mfma_frag.h"
+#include <stdlib.h>
 
 namespace dmx {
 
@@ -332,7 +333,7 @@ __device__ __forceinline__ void stage_item(const WsView& ws, const MfmaArgs& a, 
 // (rx_filter path).  A template parameter: the plain kernel carries none of the table code.
 template <bool NT, int NW, int MODE, int GSRC>
 __device__ __forceinline__ void consume_item(const WsView& ws, const MfmaArgs& a, float* __restrict__ out, int64_t work,
-                                             const ItemLds& L) {
+                                             int64_t next_work, const ItemLds& L) {
     constexpr int NTHR = NW * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const ItemPos ip = item_pos(ws, a, work);
@@ -354,6 +355,7 @@ __device__ __forceinline__ void consume_item(const WsView& ws, const MfmaArgs& a
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(o, 0, (int)((unsigned)ip.nrows * row_bytes), 0x00020000);
     const int nstrips = (int)((twoK + 31) >> 5);
     const int ntiles = (ip.nrows + 31) >> 5;
+    unsigned touched = 0;
     for (int strip = wave; strip < nstrips; strip += NW) {
         const BLane bl = b_lane(strip, col, hh, twoK, a.sc);
         h8 Bhi[4], Blo[4];
@@ -361,6 +363,20 @@ __device__ __forceinline__ void consume_item(const WsView& ws, const MfmaArgs& a
         for (int st = 0; st < 4; ++st) {
             if constexpr (GSRC == 2) load_b_step_packed(st, bl, hh, n_act, prow, a.K, Bhi[st], Blo[st]);
             else gen_b_step(st, bl, hh, n_act, L.qtab, L.crtab, L.citab, grow, a.K, gscale, Bhi[st], Blo[st]);
+        }
+        if constexpr (GSRC == 2) {
+            // The table reads are cold HBM misses in front of a dependent MFMA chain (with every user aliased to one
+            // table - L2 hits - this path is 1.3 ms per 20k users faster).  So each wave TOUCHES the lines of the strip
+            // it will load next (32 path rows x one 128-B line: one dword load by 32 lanes), one strip ahead - the
+            // next item's first strip after its last one - and finds them in L2 when it gets there.  The value is
+            // consumed by an empty asm behind this strip's fragments, so the compiler keeps the load and its wait.
+            asm volatile("" :: "v"(touched), "v"(__builtin_bit_cast(unsigned, h2{Bhi[0][0], Bhi[0][1]})));
+            const int ns = strip + NW;
+            const uint2* nrow = nullptr;
+            if (ns < nstrips) nrow = prow + (size_t)col * a.K + (size_t)ns * 16;
+            else if (next_work >= 0) nrow = a.gpack + (size_t)(next_work / a.nblk) * ws.P * a.K + (size_t)col * a.K + (size_t)wave * 16;
+            touched = 0;
+            if (nrow && hh == 0 && col < ws.P) touched = *reinterpret_cast<const volatile unsigned*>(nrow);
         }
         if constexpr (MODE != 0) {
             constexpr bool PIPE = MODE == 2;
@@ -386,7 +402,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k2_fd_mfma(WsView ws, MfmaArgs a, 
     for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
         stage_item<NW>(ws, a, w, L);
         __syncthreads();
-        consume_item<NT, NW, MODE, GSRC>(ws, a, out, w, L);
+        consume_item<NT, NW, MODE, GSRC>(ws, a, out, w, (w + gridDim.x < total) ? w + gridDim.x : (int64_t)-1, L);
         __syncthreads();                                                 // the next item's tiles overwrite these
     }
 }
@@ -740,10 +756,13 @@ static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user
     if (gtab || gpack) {                                   // rx_filter path: gains from the table (float or packed f16)
         const bool small = nstrips <= 8 && a.rows < 128;
         if (gpack) {
+            // with the fragments coming out of loads the register-lean tile loop wins at every row count: headline shape
+            // x 20k users, stage 2 in all: MODE 0 5.43 ms, MODE 1 5.85, MODE 2 (pipelined, 116 B/lane of scratch) 5.61
+            const char* m1 = getenv("DMX_LPF_TILE_MODE");             // measurement hook: 1 / 2 = the grouped / pipelined bodies
             if (small) return launch_mfma_t<true, 4, 0, 2>(ws, a, blocks, smem, out, stream, true, 0);
-            if (a.rows < 128) return launch_mfma_t<true, 8, 0, 2>(ws, a, blocks, smem, out, stream, true, ITEMS_PER_WG8);
-            if (ws.P <= 16) return launch_mfma_t<true, 8, 1, 2>(ws, a, blocks, smem, out, stream, true, ITEMS_PER_WG8);
-            return launch_mfma_t<true, 8, 2, 2>(ws, a, blocks, smem, out, stream, true, ITEMS_PER_WG8);
+            if (a.rows >= 128 && m1 && m1[0] == '1') return launch_mfma_t<true, 8, 1, 2>(ws, a, blocks, smem, out, stream, true, ITEMS_PER_WG8);
+            if (a.rows >= 128 && m1 && m1[0] == '2') return launch_mfma_t<true, 8, 2, 2>(ws, a, blocks, smem, out, stream, true, ITEMS_PER_WG8);
+            return launch_mfma_t<true, 8, 0, 2>(ws, a, blocks, smem, out, stream, true, ITEMS_PER_WG8);
         }
         if (small) return launch_mfma_t<true, 4, 0, 1>(ws, a, blocks, smem, out, stream, true, 0);
         if (a.rows < 128) return launch_mfma_t<true, 8, 0, 1>(ws, a, blocks, smem, out, stream, true, ITEMS_PER_WG8);

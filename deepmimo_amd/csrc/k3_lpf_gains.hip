@@ -147,9 +147,15 @@ __global__ __launch_bounds__(256) void k3_lpf_fft(WsView ws, LpfArgs a, int log2
 // of radix 8 (then one of radix 4 or 2 when log2 N is not a multiple of 3), each butterfly held in registers, two LDS
 // buffers per wave (ping-pong, natural order in and out - no bit reversal), twiddles from a table of the N roots of
 // unity built once per persistent workgroup, no workgroup barrier after that.  N = 512: 3 passes instead of 9 stages.
-__device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ float2 caddf(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csubf(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// complex arithmetic on (re, im) pairs as 2-vectors: the compiler emits v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32
+typedef float kv2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
+    const kv2 t = kv2{a.x, a.x} * kv2{b.x, b.y};
+    const kv2 r = __builtin_elementwise_fma(kv2{-a.y, a.y}, kv2{b.y, b.x}, t);
+    return make_float2(r[0], r[1]);
+}
+__device__ __forceinline__ float2 caddf(float2 a, float2 b) { const kv2 r = kv2{a.x, a.y} + kv2{b.x, b.y}; return make_float2(r[0], r[1]); }
+__device__ __forceinline__ float2 csubf(float2 a, float2 b) { const kv2 r = kv2{a.x, a.y} - kv2{b.x, b.y}; return make_float2(r[0], r[1]); }
 __device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }          // a * (-j)
 
 template <int R> __device__ __forceinline__ void dft_small(float2 (&v)[R]);
@@ -204,7 +210,10 @@ __device__ __forceinline__ void fft_pass(const float2* src, float2* dst, const f
 __host__ __device__ inline size_t lpf_buf_elems(int N) { return (size_t)N + N / 16 + 1; }
 __host__ __device__ inline size_t lpf_wave_lds_bytes(int N) { return (size_t)N * 8 + 4 * 2 * lpf_buf_elems(N) * 8; }
 
-__global__ __launch_bounds__(256) void k3_lpf_fft_wave(WsView ws, LpfArgs a, int log2n, int64_t user_count) {
+#ifndef K3_WAVES_PER_SIMD
+#define K3_WAVES_PER_SIMD 4
+#endif
+__global__ __launch_bounds__(256, K3_WAVES_PER_SIMD) void k3_lpf_fft_wave(WsView ws, LpfArgs a, int log2n, int64_t user_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int N = a.N;
     float2* W = reinterpret_cast<float2*>(smem);                                 // [N] exp(-j 2pi m / N)
@@ -218,32 +227,54 @@ __global__ __launch_bounds__(256) void k3_lpf_fft_wave(WsView ws, LpfArgs a, int
         W[m] = make_float2(c, s);
     }
     __syncthreads();
+    // the selected bins are the same for every user and path: up to 8 per lane stay in registers (K <= 512)
+    constexpr int NBIN = 8;
+    int binreg[NBIN];
+#pragma unroll
+    for (int j = 0; j < NBIN; ++j) { const int k = lane + 64 * j; binreg[j] = k < a.K ? fpad(a.sc[k] & (N - 1)) : 0; }
+    const bool bins_in_regs = a.K <= 64 * NBIN;
     for (int64_t ul = blockIdx.x; ul < user_count; ul += gridDim.x) {
         const int64_t u = a.user_begin + ul;
         const int n_keep = ws.n_keep[u];
+        // path records of this user, one per lane, read ONCE (a load per path in front of its transform left the wave
+        // waiting ~2 us of memory latency per path); sin(pi dn) for all paths in parallel
+        const size_t rb = (size_t)u * ws.P;
+        const bool lok = lane < n_keep;
+        const float dn_l = lok ? ws.dn[rb + lane] : 0.f, cr_l = lok ? ws.c_re[rb + lane] : 0.f, ci_l = lok ? ws.c_im[rb + lane] : 0.f;
+        const float dv_l = (lok && a.doppler) ? ws.dop_v[rb + lane] : 0.f, da_l = (lok && a.doppler) ? ws.dop_a[rb + lane] : 0.f;
+        const float s0_l = (float)sinpi((double)dn_l);
         float gsl = 1.0f;
         if (a.pack) {
             // the operand scale k2_fd_mfma's stage_item derives for this user: max |c| component -> [512, 1024), two
             // more bits of headroom for the sinc sum
-            float m = 0.f;
-            if (lane < (n_keep < 32 ? n_keep : 32)) m = fmaxf(fabsf(ws.c_re[(size_t)u * ws.P + lane]), fabsf(ws.c_im[(size_t)u * ws.P + lane]));
+            float m = lane < (n_keep < 32 ? n_keep : 32) ? fmaxf(fabsf(cr_l), fabsf(ci_l)) : 0.f;
             for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
             int e;
             (void)frexpf(m, &e);
             gsl = ldexpf(1.0f, 8 - e);
         }
         for (int l = wave; l < n_keep; l += 4) {
-            const size_t rec = (size_t)u * ws.P + l;
-            const double dn = (double)ws.dn[rec];
-            const float cr = ws.c_re[rec], ci = ws.c_im[rec];
+            float dnf, cr, ci, s0, dvf, daf;
+            if (l < 64) {                                                        // wave-uniform
+                dnf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dn_l), l));
+                cr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cr_l), l));
+                ci = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ci_l), l));
+                s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s0_l), l));
+                dvf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv_l), l));
+                daf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, da_l), l));
+            } else {                                                             // beyond 64 kept paths: read per path
+                dnf = ws.dn[rb + l]; cr = ws.c_re[rb + l]; ci = ws.c_im[rb + l];
+                s0 = (float)sinpi((double)dnf);
+                dvf = a.doppler ? ws.dop_v[rb + l] : 0.f; daf = a.doppler ? ws.dop_a[rb + l] : 0.f;
+            }
+            const double dv = (double)dvf, da = (double)daf;
             // np.sinc(d - dn) = sin(pi (d - dn)) / (pi (d - dn)) with sin(pi (d - dn)) = -(-1)^d sin(pi dn)
-            const float s0 = (float)sinpi(dn);
-            const double dv = a.doppler ? (double)ws.dop_v[rec] : 0.0, da = a.doppler ? (double)ws.dop_a[rec] : 0.0;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");               // the previous path's gather has read bufA/bufB
             __builtin_amdgcn_wave_barrier();
             for (int d = lane; d < N; d += 64) {
-                const double x = (double)d - dn;
-                const float sn = x == 0.0 ? 1.0f : ((d & 1) ? s0 : -s0) / (float)(LPF_PI * x);
+                // d - dn in float32: a multiple of ulp(dn) below 2^12, exact unless dn is tiny (then 6e-8 relative)
+                const float x = (float)d - dnf;
+                const float sn = x == 0.0f ? 1.0f : ((d & 1) ? s0 : -s0) * __builtin_amdgcn_rcpf((float)LPF_PI * x);
                 float hr = cr * sn, hi = ci * sn;
                 if (a.doppler) {
                     const double tau = a.ts * (double)d;
@@ -270,16 +301,33 @@ __global__ __launch_bounds__(256) void k3_lpf_fft_wave(WsView ws, LpfArgs a, int
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
             float2* grow = a.gtab + ((size_t)ul * ws.P + l) * a.K;
-            if (a.pack) {
-                uint2* prow = reinterpret_cast<uint2*>(grow);
-                for (int k = lane; k < a.K; k += 64) {
-                    const float2 g = src[fpad(a.sc[k] & (N - 1))];
-                    h2 hi, lo;
-                    split2_f16(g.x * gsl, g.y * gsl, hi, lo);
-                    prow[k] = make_uint2(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo));
+            uint2* prow = reinterpret_cast<uint2*>(grow);
+            if (bins_in_regs) {
+#pragma unroll
+                for (int j = 0; j < NBIN; ++j) {
+                    const int k = lane + 64 * j;
+                    if (k < a.K) {
+                        const float2 g = src[binreg[j]];
+                        if (a.pack) {
+                            h2 hi, lo;
+                            split2_f16(g.x * gsl, g.y * gsl, hi, lo);
+                            prow[k] = make_uint2(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo));
+                        } else {
+                            grow[k] = g;
+                        }
+                    }
                 }
             } else {
-                for (int k = lane; k < a.K; k += 64) grow[k] = src[fpad(a.sc[k] & (N - 1))];   // N is a power of two: floor-mod
+                for (int k = lane; k < a.K; k += 64) {
+                    const float2 g = src[fpad(a.sc[k] & (N - 1))];                // N is a power of two: floor-mod
+                    if (a.pack) {
+                        h2 hi, lo;
+                        split2_f16(g.x * gsl, g.y * gsl, hi, lo);
+                        prow[k] = make_uint2(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo));
+                    } else {
+                        grow[k] = g;
+                    }
+                }
             }
         }
     }
@@ -299,8 +347,10 @@ static int launch_channels_fd_lpf_once(const dmx_params& prm, const WsView& ws, 
 int launch_channels_fd_lpf(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
                            float2* gtab, float2* out, hipStream_t stream) {
     if (user_count == 0 || prm.n_selected == 0) return DMX_OK;
-    // 20k users at the headline shape: one launch 6.31 ms, chunks of 512 7.60, 1024 6.75, 2048 6.09, 4096 6.62
-    int64_t chunk = (size_t)ws.P * prm.n_selected * 8 * 2048 <= ((size_t)224 << 20) ? 2048 : 0;
+    // 20k users at the headline shape, before the contraction touched its next strip's table lines ahead of time: one
+    // launch 6.31 ms, chunks of 512 7.60, 1024 6.75, 2048 6.09, 4096 6.62; with the touch 5.88 in one launch, 6.06 in
+    // chunks of 2048 - so one launch is the default and the chunking stays a measurement hook
+    int64_t chunk = 0;
     const char* env = getenv("DMX_LPF_CHUNK");                       // measurement hook: users per chunk, 0 = one launch
     if (env) chunk = atoll(env);
     if (chunk <= 0 || chunk >= user_count) return launch_channels_fd_lpf_once(prm, ws, user_begin, user_count, gtab, out, stream);
