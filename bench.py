@@ -186,7 +186,7 @@ def library_id():
         return hashlib.sha256(f.read()).hexdigest()[:12]
 
 
-def measured_traffic(workload, n_ue, variant):
+def measured_traffic(workload, n_ue, variant, what="hbm_bytes_per_launch"):
     """HBM bytes per stage-2 launch from the committed rocprofv3 PMC passes (profiles/traffic.json:
     WRITE_SIZE + 2 x FETCH_SIZE, separate --pmc runs, gfx950 FETCH correction applied; written by
     tools/make_traffic_json.py).  Counters cannot be collected inside this process, so the figure comes from the
@@ -202,6 +202,8 @@ def measured_traffic(workload, n_ue, variant):
             return None, "committed PMC profile is for another user count / kernel variant"
         if e.get("library_id") != library_id():
             return None, f"committed PMC profile ({e.get('profile', '?')}) was taken on library build {e.get('library_id')}, this run is {library_id()}"
+        if what == "mfma_busy_frac":
+            return e.get("mfma_busy_frac"), f"SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), {e.get('profile', '?')}, this library build"
         return e["hbm_bytes_per_launch"], f"rocprofv3 PMC passes {e.get('profile', '?')} on this library build"
     except Exception as ex:                                    # a missing / malformed profile is not a bench failure
         return None, f"profiles/traffic.json unreadable: {ex}"
@@ -340,8 +342,9 @@ def main():
         # the matrix cores execute 3 split terms on 32 padded path slots, i.e. 3 * 32/25 times that
         flops = 8.0 * cmacs
         ach = flops / (k2_ms * 1e-3) / 1e12
+        busy, busy_note = measured_traffic(args.workload, n_ue, args.variant, "mfma_busy_frac")
         roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / MFMA_F16_PEAK_TFLOPS, "traffic": None,
+                "frac": ach / MFMA_F16_PEAK_TFLOPS, "traffic": None, "mfma_busy_frac": busy, "mfma_busy_note": busy_note,
                 "kernel": "k2c_beam_power (+ k2b_beam_project)", "kernel_ms": k2_ms,
                 "algorithmic_flops_per_launch": flops,
                 "executed_mfma_flops_per_launch": 2.0 * n_ue * ((rows + 31) // 32 * 32) * (2 * w["N"]) * 64 * 3,

@@ -138,9 +138,12 @@ __device__ __forceinline__ uint32_t float_order_key(float f) {
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
-// LPU = lanes per user (32: two users share a wave; 64: one user per wave, any path count)
-template <int LPU>
-__global__ __launch_bounds__(256) void k1_path_prep(PrepArgs a) {
+// LPU = lanes per user (32: two users share a wave; 64: one user per wave, any path count).
+// LEAN = nothing needs the angles as numbers (no FoV, isotropic patterns, no angle / power side outputs - what
+// compute_channels and bench.py run): the arccos / atan2 / FoV / dipole code is compiled out, which takes the kernel
+// from 228 to far fewer registers, i.e. from 2 to 3-4 waves per SIMD on a kernel that waits on its loads and stores.
+template <int LPU, bool LEAN>
+__global__ __launch_bounds__(256, LEAN ? 4 : 2) void k1_path_prep(PrepArgs a) {
     constexpr int UPW = 64 / LPU;                           // users per wave
     const int lane = threadIdx.x & (LPU - 1);               // lane inside the user's group
     const int grp = (threadIdx.x & 63) / LPU;               // which group of the wave
@@ -189,20 +192,22 @@ __global__ __launch_bounds__(256) void k1_path_prep(PrepArgs a) {
         // arccos is NaN outside [-1, 1]; np.angle is NaN only for NaN input
         double th_t = (isnan(zc_t) || fabs(zc_t) > 1.0) ? nan64 : 0.0, ph_t = (isnan(re_t) || isnan(im_t)) ? nan64 : 0.0;
         double th_r = (isnan(zc_r) || fabs(zc_r) > 1.0) ? nan64 : 0.0, ph_r = (isnan(re_r) || isnan(im_r)) ? nan64 : 0.0;
-        if (a.need_angles) {                                 // wave-uniform
-            th_t = acos(zc_t); ph_t = atan2(im_t, re_t);
-            th_r = acos(zc_r); ph_r = atan2(im_r, re_r);
-        }
-        if (in) {
-            if (a.side.aod_el_rot) a.side.aod_el_rot[srow + j] = th_t;
-            if (a.side.aod_az_rot) a.side.aod_az_rot[srow + j] = ph_t;
-            if (a.side.aoa_el_rot) a.side.aoa_el_rot[srow + j] = th_r;
-            if (a.side.aoa_az_rot) a.side.aoa_az_rot[srow + j] = ph_r;
+        if constexpr (!LEAN) {
+            if (a.need_angles) {                             // wave-uniform
+                th_t = acos(zc_t); ph_t = atan2(im_t, re_t);
+                th_r = acos(zc_r); ph_r = atan2(im_r, re_r);
+            }
+            if (in) {
+                if (a.side.aod_el_rot) a.side.aod_el_rot[srow + j] = th_t;
+                if (a.side.aod_az_rot) a.side.aod_az_rot[srow + j] = ph_t;
+                if (a.side.aoa_el_rot) a.side.aoa_el_rot[srow + j] = th_r;
+                if (a.side.aoa_az_rot) a.side.aoa_az_rot[srow + j] = ph_r;
+            }
         }
 
         // field of view (dataset.py:493-511): outside -> angles become NaN
         bool mask = true;
-        if (a.fov_enabled) {
+        if (!LEAN && a.fov_enabled) {
             if (a.bs_restricted) mask = mask && in_fov(th_t, ph_t, a.bs_fh, a.bs_fv);
             if (a.ue_restricted) mask = mask && in_fov(th_r, ph_r, a.ue_fh, a.ue_fv);
             mask = mask && in;
@@ -223,16 +228,18 @@ __global__ __launch_bounds__(256) void k1_path_prep(PrepArgs a) {
         const float p10 = power / 10.0f;
         const float pl = exp10f(p10);                        // float32 pow, as NumPy evaluates 10**float32
         double pw;
-        if (iso) {
+        if (LEAN || iso) {
             pw = (double)pl;
         } else {
             const double gt = a.bs_pat == DMX_PATTERN_HALFWAVE_DIPOLE ? dipole_gain(th_t) : 1.0;
             const double gr = a.ue_pat == DMX_PATTERN_HALFWAVE_DIPOLE ? dipole_gain(th_r) : 1.0;
             pw = (double)pl * (gt * gr);
         }
-        if (in) {
-            if (a.side.power_linear) a.side.power_linear[srow + j] = pl;
-            if (a.side.power_linear_ant_gain) a.side.power_linear_ant_gain[srow + j] = pw;
+        if constexpr (!LEAN) {
+            if (in) {
+                if (a.side.power_linear) a.side.power_linear[srow + j] = pl;
+                if (a.side.power_linear_ant_gain) a.side.power_linear_ant_gain[srow + j] = pw;
+            }
         }
 
         // per-path record for the first P paths (dataset.py:258-261)
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(256) void k1_path_prep(PrepArgs a) {
             dn = delay / a.ts32;                             // float32 / float32 (channel.py:183)
             double pwc = pw;
             if (dn >= (float)a.n_sc) { pwc = 0.0; dn = (float)a.n_sc; }   // channel.py:187-189
-            if (iso) {
+            if (LEAN || iso) {
                 const float amp = sqrtf((float)pwc / (float)a.n_sc);      // float32 (channel.py:192)
                 c_re = amp * e_re; c_im = amp * e_im;
             } else {
@@ -271,7 +278,7 @@ __global__ __launch_bounds__(256) void k1_path_prep(PrepArgs a) {
             keep = valid && ang_ok && !isnan(ph_t) && !isnan(ph_r) && !isnan(c_re) && !isnan(c_im) && !isnan(dn) &&
                    (c_re != 0.0f || c_im != 0.0f);          // clipped / zero-gain paths add exactly 0
         } else {
-            if (iso) {
+            if (LEAN || iso) {
                 const float amp = sqrtf((float)pw);                        // channel.py:286
                 c_re = amp * e_re; c_im = amp * e_im;
             } else {
@@ -341,12 +348,15 @@ int launch_path_prep(const dmx_rays& rays, const dmx_params& prm, const WsView& 
     a.need_angles = prm.fov_enabled || prm.bs_pattern != DMX_PATTERN_ISOTROPIC || prm.ue_pattern != DMX_PATTERN_ISOTROPIC ||
                     side.aod_el_rot || side.aod_az_rot || side.aoa_el_rot || side.aoa_az_rot;
     if (rays.n_ue == 0) return DMX_OK;
+    const bool lean = !a.need_angles && !side.power_linear && !side.power_linear_ant_gain && !side.fov_mask;
     if (rays.n_paths <= 32) {
         const unsigned grid = (unsigned)((rays.n_ue + 7) / 8);
-        hipLaunchKernelGGL(k1_path_prep<32>, dim3(grid), dim3(256), 0, stream, a);
+        if (lean) hipLaunchKernelGGL((k1_path_prep<32, true>), dim3(grid), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((k1_path_prep<32, false>), dim3(grid), dim3(256), 0, stream, a);
     } else {
         const unsigned grid = (unsigned)((rays.n_ue + 3) / 4);
-        hipLaunchKernelGGL(k1_path_prep<64>, dim3(grid), dim3(256), 0, stream, a);
+        if (lean) hipLaunchKernelGGL((k1_path_prep<64, true>), dim3(grid), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((k1_path_prep<64, false>), dim3(grid), dim3(256), 0, stream, a);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("k1_path_prep launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }

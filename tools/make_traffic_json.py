@@ -28,12 +28,21 @@ def main():
     sys.path.insert(0, ROOT)
     import bench
     w_kib, f_kib = k2_value(wcsv, "WRITE_SIZE", kernel), k2_value(fcsv, "FETCH_SIZE", kernel)
+    # matrix-core busy fraction of the same kernel when the SQ / GRBM pass is beside the TCC passes:
+    # SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over SIMDs) / (GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 x 1024 SIMDs)
+    mfma_busy = None
+    import glob
+    for g in glob.glob(os.path.join(os.path.dirname(os.path.dirname(wcsv)).replace("_pmc_WRITE_SIZE", "_pmc_GRBM*"), "*", "*counter_collection.csv")):
+        try:
+            mfma_busy = k2_value(g, "SQ_VALU_MFMA_BUSY_CYCLES", kernel) / (k2_value(g, "GRBM_GUI_ACTIVE", kernel) / 8 * 1024)
+        except SystemExit:
+            pass
     out = os.path.join(ROOT, "profiles", "traffic.json")
     t = json.load(open(out)) if os.path.exists(out) else {}
     t[workload] = {"users": users, "variant": variant, "write_size_kib": w_kib, "fetch_size_kib": f_kib,
                    "hbm_bytes_per_launch": w_kib * 1024 + 2 * f_kib * 1024,
                    "note": "WRITE_SIZE + 2 x FETCH_SIZE (gfx950: FETCH_SIZE counts half of a wide coalesced read)",
-                   "profile": tag, "library_id": bench.library_id()}
+                   "mfma_busy_frac": mfma_busy, "profile": tag, "library_id": bench.library_id()}
     json.dump(t, open(out, "w"), indent=1)
     print(json.dumps(t[workload]))
 
