@@ -44,10 +44,12 @@ struct FoldArgs {
     int M, K;
     int sc_first, sc_stride;
     double inv_n;
-    int ch;            // subcarrier blocks per work item (chunk)
+    int ch;            // subcarrier blocks per E1 table (inner chunk)
+    int sch;           // subcarrier blocks per work item (multiple of ch): E2' is built once per item
     int nblk;          // ceil(K / 16)
     int nchunk;        // ceil(nblk / ch)
-    int nb_last;       // blocks of the last chunk
+    int nsuper;        // ceil(nblk / sch): work items per user
+    int nb_last;       // blocks of the last inner chunk
     int tab_rows;      // rows of the row tables (multiple of 32)
     int k_tail;        // K - 16*(nblk-1): valid subcarriers of the last block (1..16)
 };
@@ -85,7 +87,7 @@ __host__ __device__ inline size_t fold_static_bytes(int tab_rows, int M) { retur
 __host__ __device__ inline size_t fold_wave_bytes(int M, int ch) { return 256 + (size_t)(M + ch) * FOLD_TROW; }
 
 template <bool NT>
-__global__ __launch_bounds__(256, 4) void k2_fd_fold(WsView ws, FoldArgs a, float* __restrict__ out, int64_t items) {
+__global__ __launch_bounds__(256, 5) void k2_fd_fold(WsView ws, FoldArgs a, float* __restrict__ out, int64_t items) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* rowoff0 = reinterpret_cast<uint32_t*>(smem);                 // [tab_rows] byte offset of row (a,p), full chunk
     uint32_t* rowoff1 = rowoff0 + a.tab_rows;                              // [tab_rows] same for the last chunk
@@ -132,20 +134,19 @@ __global__ __launch_bounds__(256, 4) void k2_fd_fold(WsView ws, FoldArgs a, floa
     const size_t user_floats = (size_t)M * K * 2;
 
     for (int64_t item = (int64_t)blockIdx.x * 4 + wave; item < items; item += (int64_t)gridDim.x * 4) {
-        const int64_t ul = item / a.nchunk;
-        const int chunk = (int)(item - ul * a.nchunk);
+        const int64_t ul = item / a.nsuper;
+        const int sc = (int)(item - ul * a.nsuper);
         const int64_t u = a.user_begin + ul;
-        const bool last = chunk == a.nchunk - 1;
-        const int nb = last ? a.nb_last : a.ch;                            // subcarrier blocks of this item
-        const int a0 = chunk * a.ch;
-        float* __restrict__ o = out + (size_t)ul * user_floats + (size_t)a0 * 32;
+        const int b0 = sc * a.sch;                                         // first subcarrier block of this item
+        const int bn = (a.nblk - b0) < a.sch ? (a.nblk - b0) : a.sch;      // its blocks
         int n_act = ws.n_keep[u];
         n_act = n_act < 32 ? n_act : 32;
         if (n_act == 0) {                                                  // channel.py:270-271
-            const int k0 = a0 * 16, k1 = (k0 + nb * 16) < K ? (k0 + nb * 16) : K;
+            float* __restrict__ oz = out + (size_t)ul * user_floats + (size_t)b0 * 32;
+            const int k0 = b0 * 16, k1 = (k0 + bn * 16) < K ? (k0 + bn * 16) : K;
             const int nfl = (k1 - k0) * 2;
             for (int p = 0; p < M; ++p)
-                for (int i = lane; i < nfl; i += 64) o[(size_t)p * K * 2 + i] = 0.f;
+                for (int i = lane; i < nfl; i += 64) oz[(size_t)p * K * 2 + i] = 0.f;
             continue;
         }
         // ---- path records of this user: lane (and lane + 32) = path slot
@@ -175,15 +176,6 @@ __global__ __launch_bounds__(256, 4) void k2_fd_fold(WsView ws, FoldArgs a, floa
             sincos_rev(frac_rev(ph), s, c);
             *reinterpret_cast<float2*>(Ac + (size_t)p * FOLD_TROW + lp * 8) = make_float2(cgr * c - cgi * s, cgr * s + cgi * c);
         }
-        // E1[a][l] = e^{-j 2pi q_l sc(16 (a0 + a))}; q = qh + ql with qh a multiple of 2^-12, so qh * (sc mod 4096) is
-        // exact in float32 and qh * (sc - sc mod 4096) is an integer (k2_channel_fd_mfma.hip gen_b_step)
-        for (int ab = hh; ab < nb; ab += 2) {
-            const int sca = a.sc_first + a.sc_stride * 16 * (a0 + ab);
-            const float p1 = qhf * (float)(sca & 4095);
-            float s, c;
-            sincos_rev(fmaf(qlf, (float)sca, p1 - rintf(p1)), s, c);
-            *reinterpret_cast<float2*>(E1 + (size_t)ab * FOLD_TROW + lp * 8) = make_float2(c, -s);
-        }
         wave_lds_sync();
 
         // ---- E2' fragments (B operand, 32 columns = 16 subcarrier offsets x {re, im}); element j of K-step s is row
@@ -209,6 +201,24 @@ __global__ __launch_bounds__(256, 4) void k2_fd_fold(WsView ws, FoldArgs a, floa
                 }
             }
         }
+
+        // ---- inner chunks of <= ch subcarrier blocks: one E1 table each, the same E2' fragments for all of them
+        for (int c0 = 0; c0 < bn; c0 += a.ch) {
+        const int a0 = b0 + c0;
+        const int nb = (bn - c0) < a.ch ? (bn - c0) : a.ch;
+        const bool last = a0 + nb == a.nblk;
+        float* __restrict__ o = out + (size_t)ul * user_floats + (size_t)a0 * 32;
+        wave_lds_sync();                                                   // the previous chunk's tiles have read E1
+        // E1[a][l] = e^{-j 2pi q_l sc(16 (a0 + a))}; q = qh + ql with qh a multiple of 2^-12, so qh * (sc mod 4096) is
+        // exact in float32 and qh * (sc - sc mod 4096) is an integer (k2_channel_fd_mfma.hip gen_b_step)
+        for (int ab = hh; ab < nb; ab += 2) {
+            const int sca = a.sc_first + a.sc_stride * 16 * (a0 + ab);
+            const float p1 = qhf * (float)(sca & 4095);
+            float s, c;
+            sincos_rev(fmaf(qlf, (float)sca, p1 - rintf(p1)), s, c);
+            *reinterpret_cast<float2*>(E1 + (size_t)ab * FOLD_TROW + lp * 8) = make_float2(c, -s);
+        }
+        wave_lds_sync();
 
         // ---- row tiles: 32 rows (a,p) each
         const uint32_t* rowoff = last ? rowoff1 : rowoff0;
@@ -272,6 +282,7 @@ __global__ __launch_bounds__(256, 4) void k2_fd_fold(WsView ws, FoldArgs a, floa
                 }
             }
         }
+        }                                                                  // inner chunks
     }
 }
 
@@ -282,18 +293,23 @@ bool fd_fold_supported(const dmx_params& prm, const WsView& ws) {
     return prm.sc_stride > 0 && prm.n_selected >= 1 && M <= FOLD_MAX_M;
 }
 
-// blocks per work item: the largest of 32 / 16 / 8 that lets at least three workgroups share a CU's 160 KiB of LDS
+// Subcarrier blocks per E1 table: the per-wave LDS tables ((M + ch) rows of 272 B) decide how many workgroups share a
+// CU, and this kernel's waves wait on memory and LDS for a good part of their time - so the largest of 32 / 16 / 8
+// that still lets FOUR workgroups (16 waves) share the 160 KiB, else three.  E2' is built once per work item whatever
+// ch is, so a smaller ch costs only its loop overhead.
+static constexpr int FOLD_SUPER = 64;            // blocks per work item (1024 subcarriers)
 static int fold_chunk_blocks(int M, int nblk, int forced) {
-    int best = 8;
     const int cand[3] = {32, 16, 8};
-    for (int ch : cand) {
-        if (forced > 0 && ch != forced) continue;
-        const int c = ch < nblk ? ch : nblk;
-        const int tab = (M * c + 31) / 32 * 32;
-        const size_t smem = fold_static_bytes(tab, M) + 4 * fold_wave_bytes(M, c);
-        if (forced > 0 || smem * 3 <= 160 * 1024) { best = ch; break; }
+    if (forced > 0) return forced < nblk ? forced : nblk;
+    for (int want = 4; want >= 3; --want) {
+        for (int ch : cand) {
+            const int c = ch < nblk ? ch : nblk;
+            const int tab = (M * c + 31) / 32 * 32;
+            const size_t smem = fold_static_bytes(tab, M) + 4 * fold_wave_bytes(M, c);
+            if (smem * want <= 160 * 1024) return c;
+        }
     }
-    return best < nblk ? best : nblk;
+    return 8 < nblk ? 8 : nblk;
 }
 
 // Automatic choice (variant 0), from profiles/r2_fold_sweep.txt (200k users x 25 paths; ms for this kernel | the best of
@@ -339,6 +355,9 @@ int launch_channels_fd_fold(const dmx_params& prm, const WsView& ws, int64_t use
         if (chunk_blocks != 8 && chunk_blocks != 16 && chunk_blocks != 32) chunk_blocks = 0;
     }
     a.ch = fold_chunk_blocks(a.M, a.nblk, chunk_blocks);
+    a.sch = (FOLD_SUPER / a.ch) * a.ch;
+    if (a.sch > a.nblk) a.sch = (a.nblk + a.ch - 1) / a.ch * a.ch;
+    a.nsuper = (a.nblk + a.sch - 1) / a.sch;
     a.nchunk = (a.nblk + a.ch - 1) / a.ch;
     a.nb_last = a.nblk - a.ch * (a.nchunk - 1);
     a.tab_rows = (a.M * a.ch + 31) / 32 * 32;
@@ -346,7 +365,7 @@ int launch_channels_fd_fold(const dmx_params& prm, const WsView& ws, int64_t use
     if ((size_t)a.M * (size_t)a.K * 8 >= (size_t)1 << 30) { set_error("%d x %d outputs per user are too many for the folded kernel", a.M, a.K); return DMX_ERR_SHAPE; }
     const size_t smem = fold_static_bytes(a.tab_rows, a.M) + 4 * fold_wave_bytes(a.M, a.ch);
     if (smem > 160 * 1024) { set_error("folded kernel tables of %zu bytes exceed LDS", smem); return DMX_ERR_SHAPE; }
-    const int64_t items = user_count * a.nchunk;
+    const int64_t items = user_count * a.nsuper;
     const void* kfn = reinterpret_cast<const void*>(k2_fd_fold<true>);
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
