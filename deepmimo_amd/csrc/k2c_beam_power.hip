@@ -10,16 +10,22 @@
 // not by memory: 105 GB of beam-space output (64 beams, headline shape) are not written and not read back.
 //
 // Mapping (one 512-thread workgroup per user, persistent): the waves own ROW tiles here (their A' fragments stay in
-// registers for the whole user), so the B' fragments of a 32-column strip are needed by every wave: each wave builds
-// ONE strip of an 8-strip chunk and parks its fragments in LDS in register layout (8 KB per strip, conflict-free
-// ds_read_b128 / ds_write_b128), then every wave runs its tile against the chunk's strips.  With fewer than eight
-// row tiles the waves also split the chunk's strips among themselves.
+// registers for the whole user), so the B' fragments are needed by every wave and live in LDS in register layout
+// (conflict-free ds_read_b128 / ds_write_b128).  Because no interleaved (re, im) stream has to come out, the real GEMM's
+// columns are NOT interleaved here: a WIDE strip covers 32 subcarriers with TWO accumulators - one whose columns are
+// the real parts (B' rows (Re G, -Im G)), one for the imaginary parts ((Im G, Re G)) - so |Y|^2 = re^2 + im^2 forms
+// inside one lane (no lane-pair exchange, no duplicated square roots), and both B' operand sets come from ONE f16 split
+// of G per (path, subcarrier): the (Re, -Im) pair is the split with the upper sign flipped, the (Im, Re) pair the same
+// word rotated by 16 bits.  Per chunk of 4 wide strips (128 subcarriers, 64 KB) each wave generates half a wide strip
+// (two K-steps), then runs its tile against the chunk; with fewer than eight row tiles the waves split the chunk's
+// wide strips among themselves.
 #include "k2_mfma_frag.h"
 
 namespace dmx {
 
 static constexpr int BP_WAVES = 8;
-static constexpr int BP_SLOT = 8 * 1024;        // one strip's B' fragments: 4 K-steps x {hi, lo} x 64 lanes x 16 B
+static constexpr int BP_SLOT = 16 * 1024;       // one wide strip: 4 K-steps x {re hi, re lo, im hi, im lo} x 64 lanes x 16 B
+static constexpr int BP_CHUNK = 4;              // wide strips per chunk
 
 struct BeamPowArgs {
     int64_t user_begin;
@@ -36,26 +42,14 @@ struct BeamPowArgs {
 
 __host__ __device__ inline size_t beam_pow_lds_bytes(int M) {
     const size_t nblk = ((size_t)M + MAX_ROWS - 1) / MAX_ROWS;                 // per row block: 8 waves x 32 partial row sums
-    return (size_t)BP_WAVES * BP_SLOT + LPAD * (8 + 4 + 4) + 16 + nblk * BP_WAVES * 32 * 4;
-}
-
-// v[i] += (v[i] of the neighbouring lane, lane ^ 1) for the 16 squared accumulator values: one VALU instruction each
-// with the DPP operand folded in (quad_perm [1,0,3,2]; the compiler's own form of `v + dpp(v)` is v_mov_b32_dpp + add).
-// A VGPR written by a VALU instruction needs two wait states before a DPP read: one s_nop for the whole group, inside
-// the statement (the compiler pads nothing in front of an asm string).
-#define BP_DPP(n) "v_add_f32_dpp %" #n ", %" #n ", %" #n " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-__device__ __forceinline__ void pair_sums16(float (&v)[16]) {
-    asm("s_nop 1\n\t" BP_DPP(0) BP_DPP(1) BP_DPP(2) BP_DPP(3) BP_DPP(4) BP_DPP(5) BP_DPP(6) BP_DPP(7)
-        BP_DPP(8) BP_DPP(9) BP_DPP(10) BP_DPP(11) BP_DPP(12) BP_DPP(13) BP_DPP(14) BP_DPP(15)
-        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
-          "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+    return (size_t)BP_CHUNK * BP_SLOT + LPAD * (8 + 4 + 4) + 16 + nblk * BP_WAVES * 32 * 4;
 }
 
 __global__ __launch_bounds__(BP_WAVES * 64, 4) void k2c_beam_power(WsView ws, BeamPowArgs a, int64_t user_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* bbuf = smem;                                                      // [8][BP_SLOT]
+    unsigned char* bbuf = smem;                                                      // [BP_CHUNK][BP_SLOT]
     float* bbuf_f = reinterpret_cast<float*>(smem);
-    float2* qtab = reinterpret_cast<float2*>(smem + (size_t)BP_WAVES * BP_SLOT);     // [32]
+    float2* qtab = reinterpret_cast<float2*>(smem + (size_t)BP_CHUNK * BP_SLOT);     // [32]
     float* crtab = reinterpret_cast<float*>(qtab + LPAD);
     float* citab = crtab + LPAD;
     float* misc = citab + LPAD;                                                      // [4]
@@ -65,8 +59,7 @@ __global__ __launch_bounds__(BP_WAVES * 64, 4) void k2c_beam_power(WsView ws, Be
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform: tile / strip assignments stay scalar
     const int col = lane & 31, hh = lane >> 5;
     const int B = a.n_beams, M = a.M, P = ws.P;
-    const size_t twoK = (size_t)2 * a.K;
-    const int nstrips = (int)((twoK + 31) >> 5);
+    const int nwide = (a.K + 31) >> 5;                              // wide strips: 32 subcarriers each
     const int nblk = (M + MAX_ROWS - 1) / MAX_ROWS;
 
     for (int64_t ul = blockIdx.x; ul < user_count; ul += gridDim.x) {
@@ -99,7 +92,7 @@ __global__ __launch_bounds__(BP_WAVES * 64, 4) void k2c_beam_power(WsView ws, Be
             if (lane == 0) { misc[0] = ldexpf(1.0f, e - 10 - ea); misc[1] = ldexpf(1.0f, ea); misc[2] = gs; }
         }
         __syncthreads();
-        const float ascale = misc[1], gscale = misc[2];
+        const float ascale = misc[1];
 
         for (int blk = 0; blk < nblk; ++blk) {
             const int row0 = blk * MAX_ROWS;
@@ -142,43 +135,68 @@ __global__ __launch_bounds__(BP_WAVES * 64, 4) void k2c_beam_power(WsView ws, Be
 #pragma unroll
             for (int i = 0; i < 16; ++i) rowsum[i] = 0.f;
 
-            for (int c0 = 0; c0 < nstrips; c0 += BP_WAVES) {
+            for (int c0 = 0; c0 < nwide; c0 += BP_CHUNK) {
                 __syncthreads();                                                     // the previous chunk has been consumed
-                if (c0 + wave < nstrips) {
-                    const BLane bl = b_lane(c0 + wave, col, hh, twoK, a.sc);
-                    h8* slot = reinterpret_cast<h8*>(bbuf + (size_t)wave * BP_SLOT);
+                {
+                    // wave w builds K-steps 2(w&1), 2(w&1)+1 of wide strip c0 + (w>>1): lane = (subcarrier, path group)
+                    const int wsi = c0 + (wave >> 1);
+                    const int kidx = (wsi << 5) + col;
+                    const bool kok = wsi < nwide && kidx < a.K;
+                    const int kki = kok ? a.sc[kidx] : 0;
+                    const float kl = (float)(kki & 4095), kf = (float)kki;
+                    h8* slot = reinterpret_cast<h8*>(bbuf + (size_t)(wave >> 1) * BP_SLOT);
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        h8 bh, blo;
-                        gen_b_step(s, bl, hh, n_act, qtab, crtab, citab, nullptr, a.K, gscale, bh, blo);
-                        if (!bl.kok) { bh = h8{0, 0, 0, 0, 0, 0, 0, 0}; blo = bh; }  // columns past the selection add nothing
-                        slot[(2 * s) * 64 + lane] = bh;
-                        slot[(2 * s + 1) * 64 + lane] = blo;
+                    for (int t = 0; t < 2; ++t) {
+                        const int st = 2 * (wave & 1) + t;
+                        h8 rh = h8{0, 0, 0, 0, 0, 0, 0, 0}, rl = rh, ih = rh, il = rh;
+                        if (kok && 8 * st < n_act) {
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) {
+                                const int pl = 8 * st + 4 * hh + jj;
+                                const float2 q = qtab[pl];
+                                const float p1 = q.x * kl;
+                                float sn, cs;
+                                sincos_rev(fmaf(q.y, kf, p1 - rintf(p1)), sn, cs);
+                                const float cr = crtab[pl], ci = citab[pl];
+                                h2 vh, vl;
+                                split2_f16(cr * cs + ci * sn, ci * cs - cr * sn, vh, vl);       // (Re G, Im G), G = c e^{-jx}
+                                const unsigned hb = __builtin_bit_cast(unsigned, vh), lb = __builtin_bit_cast(unsigned, vl);
+                                const h2 reh = __builtin_bit_cast(h2, hb ^ 0x80000000u), rel = __builtin_bit_cast(h2, lb ^ 0x80000000u);
+                                const h2 imh = __builtin_bit_cast(h2, __builtin_amdgcn_alignbit(hb, hb, 16));
+                                const h2 iml = __builtin_bit_cast(h2, __builtin_amdgcn_alignbit(lb, lb, 16));
+                                rh[2 * jj] = reh[0]; rh[2 * jj + 1] = reh[1]; rl[2 * jj] = rel[0]; rl[2 * jj + 1] = rel[1];
+                                ih[2 * jj] = imh[0]; ih[2 * jj + 1] = imh[1]; il[2 * jj] = iml[0]; il[2 * jj + 1] = iml[1];
+                            }
+                        }
+                        slot[(4 * st + 0) * 64 + lane] = rh;
+                        slot[(4 * st + 1) * 64 + lane] = rl;
+                        slot[(4 * st + 2) * 64 + lane] = ih;
+                        slot[(4 * st + 3) * 64 + lane] = il;
                     }
                 }
                 __syncthreads();
                 if (active) {
-                    for (int j = grp; j < BP_WAVES && c0 + j < nstrips; j += ngrp) {
+                    for (int j = grp; j < BP_CHUNK && c0 + j < nwide; j += ngrp) {
                         const h8* slot = reinterpret_cast<const h8*>(bbuf + (size_t)j * BP_SLOT);
-                        f16v acc;
+                        f16v are, aim;
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+                        for (int i = 0; i < 16; ++i) { are[i] = 0.f; aim[i] = 0.f; }
 #pragma unroll
                         for (int s = 0; s < 4; ++s) {
                             if (8 * s < n_act) {
-                                const h8 bh = slot[(2 * s) * 64 + lane], blo = slot[(2 * s + 1) * 64 + lane];
-                                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[s], bh, acc, 0, 0, 0);
-                                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[s], blo, acc, 0, 0, 0);
-                                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[s], bh, acc, 0, 0, 0);
+                                const h8 rh = slot[(4 * s + 0) * 64 + lane], rl = slot[(4 * s + 1) * 64 + lane];
+                                const h8 ih = slot[(4 * s + 2) * 64 + lane], il = slot[(4 * s + 3) * 64 + lane];
+                                are = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[s], rh, are, 0, 0, 0);
+                                aim = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[s], ih, aim, 0, 0, 0);
+                                are = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[s], rl, are, 0, 0, 0);
+                                aim = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[s], il, aim, 0, 0, 0);
+                                are = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[s], rh, are, 0, 0, 0);
+                                aim = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[s], ih, aim, 0, 0, 0);
                             }
                         }
-                        // |Y| of the (re, im) lane pair; both lanes of a pair add the same value (halved at the end)
-                        float sq[16];
+                        // |Y| of this lane's subcarrier for the 16 rows it holds: both parts are in this lane
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) sq[i] = acc[i] * acc[i];
-                        pair_sums16(sq);
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) rowsum[i] += __builtin_amdgcn_sqrtf(sq[i]);
+                        for (int i = 0; i < 16; ++i) rowsum[i] += __builtin_amdgcn_sqrtf(fmaf(are[i], are[i], aim[i] * aim[i]));
                     }
                 }
             }
@@ -187,7 +205,7 @@ __global__ __launch_bounds__(BP_WAVES * 64, 4) void k2c_beam_power(WsView ws, Be
                 for (int i = 0; i < 16; ++i) {
                     float v = rowsum[i];
                     for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
-                    if (col == 0) rs[((blk * BP_WAVES + wave) << 5) + (i & 3) + 8 * (i >> 2) + 4 * hh] = 0.5f * v;
+                    if (col == 0) rs[((blk * BP_WAVES + wave) << 5) + (i & 3) + 8 * (i >> 2) + 4 * hh] = v;
                 }
             }
         }
