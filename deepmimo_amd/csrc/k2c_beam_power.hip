@@ -16,16 +16,17 @@
 // the real parts (B' rows (Re G, -Im G)), one for the imaginary parts ((Im G, Re G)) - so |Y|^2 = re^2 + im^2 forms
 // inside one lane (no lane-pair exchange, no duplicated square roots), and both B' operand sets come from ONE f16 split
 // of G per (path, subcarrier): the (Re, -Im) pair is the split with the upper sign flipped, the (Im, Re) pair the same
-// word rotated by 16 bits.  Per chunk of 4 wide strips (128 subcarriers, 64 KB) each wave generates half a wide strip
-// (two K-steps), then runs its tile against the chunk; with fewer than eight row tiles the waves split the chunk's
-// wide strips among themselves.
+// word rotated by 16 bits.  Chunks of 2 wide strips (64 subcarriers, 32 KB) in two buffers: each wave generates one
+// K-step of one wide strip of chunk c + 1, then runs its tile against chunk c - one barrier per chunk; with fewer than
+// eight row tiles the waves split the chunk's wide strips among themselves.
 #include "k2_mfma_frag.h"
 
 namespace dmx {
 
 static constexpr int BP_WAVES = 8;
 static constexpr int BP_SLOT = 16 * 1024;       // one wide strip: 4 K-steps x {re hi, re lo, im hi, im lo} x 64 lanes x 16 B
-static constexpr int BP_CHUNK = 4;              // wide strips per chunk
+static constexpr int BP_CHUNK = 2;              // wide strips per chunk (8 waves x one K-step of one wide strip)
+static constexpr int BP_BUFS = 2;               // chunk buffers: generation of chunk c + 1 beside the products of chunk c
 
 struct BeamPowArgs {
     int64_t user_begin;
@@ -42,14 +43,14 @@ struct BeamPowArgs {
 
 __host__ __device__ inline size_t beam_pow_lds_bytes(int M) {
     const size_t nblk = ((size_t)M + MAX_ROWS - 1) / MAX_ROWS;                 // per row block: 8 waves x 32 partial row sums
-    return (size_t)BP_CHUNK * BP_SLOT + LPAD * (8 + 4 + 4) + 16 + nblk * BP_WAVES * 32 * 4;
+    return (size_t)BP_BUFS * BP_CHUNK * BP_SLOT + LPAD * (8 + 4 + 4) + 16 + nblk * BP_WAVES * 32 * 4;
 }
 
 __global__ __launch_bounds__(BP_WAVES * 64, 4) void k2c_beam_power(WsView ws, BeamPowArgs a, int64_t user_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* bbuf = smem;                                                      // [BP_CHUNK][BP_SLOT]
+    unsigned char* bbuf = smem;                                                      // [BP_BUFS][BP_CHUNK][BP_SLOT]
     float* bbuf_f = reinterpret_cast<float*>(smem);
-    float2* qtab = reinterpret_cast<float2*>(smem + (size_t)BP_CHUNK * BP_SLOT);     // [32]
+    float2* qtab = reinterpret_cast<float2*>(smem + (size_t)BP_BUFS * BP_CHUNK * BP_SLOT);     // [32]
     float* crtab = reinterpret_cast<float*>(qtab + LPAD);
     float* citab = crtab + LPAD;
     float* misc = citab + LPAD;                                                      // [4]
@@ -135,49 +136,50 @@ __global__ __launch_bounds__(BP_WAVES * 64, 4) void k2c_beam_power(WsView ws, Be
 #pragma unroll
             for (int i = 0; i < 16; ++i) rowsum[i] = 0.f;
 
-            for (int c0 = 0; c0 < nwide; c0 += BP_CHUNK) {
-                __syncthreads();                                                     // the previous chunk has been consumed
-                {
-                    // wave w builds K-steps 2(w&1), 2(w&1)+1 of wide strip c0 + (w>>1): lane = (subcarrier, path group)
-                    const int wsi = c0 + (wave >> 1);
-                    const int kidx = (wsi << 5) + col;
-                    const bool kok = wsi < nwide && kidx < a.K;
-                    const int kki = kok ? a.sc[kidx] : 0;
-                    const float kl = (float)(kki & 4095), kf = (float)kki;
-                    h8* slot = reinterpret_cast<h8*>(bbuf + (size_t)(wave >> 1) * BP_SLOT);
+            // Two buffers of BP_CHUNK wide strips: every wave first generates its share of chunk c + 1 (one K-step of
+            // one wide strip: lane = (subcarrier, path group)), then runs its tile against chunk c - generation and
+            // matrix-core work of different waves share a phase, ONE barrier per chunk.
+            auto generate = [&](int c0, int buf) {
+                const int wsi = c0 + (wave >> 2), st = wave & 3;
+                const int kidx = (wsi << 5) + col;
+                const bool kok = wsi < nwide && kidx < a.K;
+                const int kki = kok ? a.sc[kidx] : 0;
+                const float kl = (float)(kki & 4095), kf = (float)kki;
+                h8* slot = reinterpret_cast<h8*>(bbuf + (size_t)(buf * BP_CHUNK + (wave >> 2)) * BP_SLOT);
+                h8 rh = h8{0, 0, 0, 0, 0, 0, 0, 0}, rl = rh, ih = rh, il = rh;
+                if (kok && 8 * st < n_act) {
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const int st = 2 * (wave & 1) + t;
-                        h8 rh = h8{0, 0, 0, 0, 0, 0, 0, 0}, rl = rh, ih = rh, il = rh;
-                        if (kok && 8 * st < n_act) {
-#pragma unroll
-                            for (int jj = 0; jj < 4; ++jj) {
-                                const int pl = 8 * st + 4 * hh + jj;
-                                const float2 q = qtab[pl];
-                                const float p1 = q.x * kl;
-                                float sn, cs;
-                                sincos_rev(fmaf(q.y, kf, p1 - rintf(p1)), sn, cs);
-                                const float cr = crtab[pl], ci = citab[pl];
-                                h2 vh, vl;
-                                split2_f16(cr * cs + ci * sn, ci * cs - cr * sn, vh, vl);       // (Re G, Im G), G = c e^{-jx}
-                                const unsigned hb = __builtin_bit_cast(unsigned, vh), lb = __builtin_bit_cast(unsigned, vl);
-                                const h2 reh = __builtin_bit_cast(h2, hb ^ 0x80000000u), rel = __builtin_bit_cast(h2, lb ^ 0x80000000u);
-                                const h2 imh = __builtin_bit_cast(h2, __builtin_amdgcn_alignbit(hb, hb, 16));
-                                const h2 iml = __builtin_bit_cast(h2, __builtin_amdgcn_alignbit(lb, lb, 16));
-                                rh[2 * jj] = reh[0]; rh[2 * jj + 1] = reh[1]; rl[2 * jj] = rel[0]; rl[2 * jj + 1] = rel[1];
-                                ih[2 * jj] = imh[0]; ih[2 * jj + 1] = imh[1]; il[2 * jj] = iml[0]; il[2 * jj + 1] = iml[1];
-                            }
-                        }
-                        slot[(4 * st + 0) * 64 + lane] = rh;
-                        slot[(4 * st + 1) * 64 + lane] = rl;
-                        slot[(4 * st + 2) * 64 + lane] = ih;
-                        slot[(4 * st + 3) * 64 + lane] = il;
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int pl = 8 * st + 4 * hh + jj;
+                        const float2 q = qtab[pl];
+                        const float p1 = q.x * kl;
+                        float sn, cs;
+                        sincos_rev(fmaf(q.y, kf, p1 - rintf(p1)), sn, cs);
+                        const float cr = crtab[pl], ci = citab[pl];
+                        h2 vh, vl;
+                        split2_f16(cr * cs + ci * sn, ci * cs - cr * sn, vh, vl);       // (Re G, Im G), G = c e^{-jx}
+                        const unsigned hb = __builtin_bit_cast(unsigned, vh), lb = __builtin_bit_cast(unsigned, vl);
+                        const h2 reh = __builtin_bit_cast(h2, hb ^ 0x80000000u), rel = __builtin_bit_cast(h2, lb ^ 0x80000000u);
+                        const h2 imh = __builtin_bit_cast(h2, __builtin_amdgcn_alignbit(hb, hb, 16));
+                        const h2 iml = __builtin_bit_cast(h2, __builtin_amdgcn_alignbit(lb, lb, 16));
+                        rh[2 * jj] = reh[0]; rh[2 * jj + 1] = reh[1]; rl[2 * jj] = rel[0]; rl[2 * jj + 1] = rel[1];
+                        ih[2 * jj] = imh[0]; ih[2 * jj + 1] = imh[1]; il[2 * jj] = iml[0]; il[2 * jj + 1] = iml[1];
                     }
                 }
-                __syncthreads();
+                slot[(4 * st + 0) * 64 + lane] = rh;
+                slot[(4 * st + 1) * 64 + lane] = rl;
+                slot[(4 * st + 2) * 64 + lane] = ih;
+                slot[(4 * st + 3) * 64 + lane] = il;
+            };
+            __syncthreads();                                                         // the previous row block has read both buffers
+            generate(0, 0);
+            __syncthreads();
+            int buf = 0;
+            for (int c0 = 0; c0 < nwide; c0 += BP_CHUNK, buf ^= 1) {
+                if (c0 + BP_CHUNK < nwide) generate(c0 + BP_CHUNK, buf ^ 1);
                 if (active) {
                     for (int j = grp; j < BP_CHUNK && c0 + j < nwide; j += ngrp) {
-                        const h8* slot = reinterpret_cast<const h8*>(bbuf + (size_t)j * BP_SLOT);
+                        const h8* slot = reinterpret_cast<const h8*>(bbuf + (size_t)(buf * BP_CHUNK + j) * BP_SLOT);
                         f16v are, aim;
 #pragma unroll
                         for (int i = 0; i < 16; ++i) { are[i] = 0.f; aim[i] = 0.f; }
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(BP_WAVES * 64, 4) void k2c_beam_power(WsView ws, Be
                         for (int i = 0; i < 16; ++i) rowsum[i] += __builtin_amdgcn_sqrtf(fmaf(are[i], are[i], aim[i] * aim[i]));
                     }
                 }
+                __syncthreads();                       // chunk c + 1 is complete; chunk c's buffer may be overwritten
             }
             if (active) {
 #pragma unroll
