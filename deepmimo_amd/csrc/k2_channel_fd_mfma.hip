@@ -373,8 +373,9 @@ __device__ __forceinline__ void consume_item(const WsView& ws, const MfmaArgs& a
             asm volatile("" :: "v"(touched), "v"(__builtin_bit_cast(unsigned, h2{Bhi[0][0], Bhi[0][1]})));
             const int ns = strip + NW;
             const uint2* nrow = nullptr;
-            if (ns < nstrips) nrow = prow + (size_t)col * a.K + (size_t)ns * 16;
-            else if (next_work >= 0) nrow = a.gpack + (size_t)(next_work / a.nblk) * ws.P * a.K + (size_t)col * a.K + (size_t)wave * 16;
+            const int kmax = a.K - 1;                                     // stay inside the row (K need not be a multiple of 16)
+            if (ns < nstrips) nrow = prow + (size_t)col * a.K + (size_t)(ns * 16 < kmax ? ns * 16 : kmax);
+            else if (next_work >= 0) nrow = a.gpack + (size_t)(next_work / a.nblk) * ws.P * a.K + (size_t)col * a.K + (size_t)(wave * 16 < kmax ? wave * 16 : kmax);
             touched = 0;
             if (nrow && hh == 0 && col < ws.P) touched = *reinterpret_cast<const volatile unsigned*>(nrow);
         }
