@@ -36,7 +36,8 @@ typedef float ff16 __attribute__((ext_vector_type(16)));
 
 static constexpr int FOLD_TROW = 272;            // bytes per table row: 32 complex64 + 16 B pad (conflict-free ds_read_b128)
 static constexpr float FOLD_B_SCALE = 64.0f;     // 2^6 on the unit-modulus E2' operand
-static constexpr int FOLD_MAX_M = 64;
+static constexpr int FOLD_MAX_M = 128;          // u8 element indices, rowsrc packing (128 x 272 < 65536)
+static constexpr int FOLD_SHARED_FROM = 33;     // antenna pairs from which the four waves of a workgroup share one set of tables
 
 struct FoldArgs {
     int64_t user_begin;
@@ -86,7 +87,18 @@ __device__ __forceinline__ void wave_lds_sync() {
 __host__ __device__ inline size_t fold_static_bytes(int tab_rows, int M) { return (size_t)tab_rows * 12 + align_up((size_t)M * 4, 16); }
 __host__ __device__ inline size_t fold_wave_bytes(int M, int ch) { return 256 + (size_t)(M + ch) * FOLD_TROW; }
 
-template <bool NT>
+// synchronisation between writers and readers of the per-item tables: the owning wave alone (WS = 1: its DS operations
+// execute in order) or the four waves of the workgroup that share one set of tables (WS = 4)
+template <int WS>
+__device__ __forceinline__ void fold_sync() {
+    if constexpr (WS == 4) __syncthreads();
+    else wave_lds_sync();
+}
+
+// WS = waves sharing a work item: 1 - every wave owns its items and tables (few antenna pairs: the tables are small, no
+// workgroup barrier anywhere); 4 - the workgroup works on one item with ONE set of tables and splits its row tiles over
+// the waves (33 ... 128 pairs: per-wave tables would leave one workgroup per CU).
+template <bool NT, int WS>
 __global__ __launch_bounds__(256, 5) void k2_fd_fold(WsView ws, FoldArgs a, float* __restrict__ out, int64_t items) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* rowoff0 = reinterpret_cast<uint32_t*>(smem);                 // [tab_rows] byte offset of row (a,p), full chunk
@@ -98,7 +110,7 @@ __global__ __launch_bounds__(256, 5) void k2_fd_fold(WsView ws, FoldArgs a, floa
     // pointers, the output buffer descriptor, the path count - in scalar registers (a descriptor in vector registers
     // makes every buffer_store a readfirstlane waterfall loop)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned char* wbase = smem + fold_static_bytes(a.tab_rows, a.M) + (size_t)wave * fold_wave_bytes(a.M, a.ch);
+    unsigned char* wbase = smem + fold_static_bytes(a.tab_rows, a.M) + (WS == 1 ? (size_t)wave * fold_wave_bytes(a.M, a.ch) : (size_t)0);
     float2* qtab = reinterpret_cast<float2*>(wbase);                       // [32] q_l as (multiple of 2^-12, remainder)
     unsigned char* Ac = wbase + 256;                                       // [M][FOLD_TROW]  c_l a_rx a_tx (scaled)
     unsigned char* E1 = Ac + (size_t)a.M * FOLD_TROW;                      // [ch][FOLD_TROW] e^{-j 2pi q_l sc(16 a)}
@@ -133,7 +145,9 @@ __global__ __launch_bounds__(256, 5) void k2_fd_fold(WsView ws, FoldArgs a, floa
     const uint32_t lmask_last = bsc < a.k_tail ? 0x7FFFFFFFu : 0xFFFFFFFFu;
     const size_t user_floats = (size_t)M * K * 2;
 
-    for (int64_t item = (int64_t)blockIdx.x * 4 + wave; item < items; item += (int64_t)gridDim.x * 4) {
+    constexpr int IW = 4 / WS;                                             // work items a workgroup has in flight
+    const int sub = WS == 4 ? wave : 0;                                    // this wave's share of table rows / row tiles
+    for (int64_t item = (int64_t)blockIdx.x * IW + (WS == 1 ? wave : 0); item < items; item += (int64_t)gridDim.x * IW) {
         const int64_t ul = item / a.nsuper;
         const int sc = (int)(item - ul * a.nsuper);
         const int64_t u = a.user_begin + ul;
@@ -145,7 +159,7 @@ __global__ __launch_bounds__(256, 5) void k2_fd_fold(WsView ws, FoldArgs a, floa
             float* __restrict__ oz = out + (size_t)ul * user_floats + (size_t)b0 * 32;
             const int k0 = b0 * 16, k1 = (k0 + bn * 16) < K ? (k0 + bn * 16) : K;
             const int nfl = (k1 - k0) * 2;
-            for (int p = 0; p < M; ++p)
+            for (int p = sub; p < M; p += WS)
                 for (int i = lane; i < nfl; i += 64) oz[(size_t)p * K * 2 + i] = 0.f;
             continue;
         }
@@ -165,10 +179,10 @@ __global__ __launch_bounds__(256, 5) void k2_fd_fold(WsView ws, FoldArgs a, floa
         const double qh = rint(q * 4096.0) * (1.0 / 4096.0);
         const float qhf = (float)qh, qlf = (float)(q - qh);
         const float cgr = cr * gs, cgi = ci * gs;
-        wave_lds_sync();                                                   // the previous item's table reads are done
-        if (lane < 32) qtab[lane] = make_float2(qhf, qlf);
+        fold_sync<WS>();                                                   // the previous item's table reads are done
+        if (lane < 32 && sub == 0) qtab[lane] = make_float2(qhf, qlf);
         // Ac[p][l] = c_l a_rx[rx,l] a_tx[tx,l]   (geometry.py:85-102; phases in float64 revolutions)
-        for (int p = hh; p < M; p += 2) {
+        for (int p = 2 * sub + hh; p < M; p += 2 * WS) {
             const uint32_t ix = pidx[p];
             const double ph = (double)(ix & 255u) * rxy + (double)((ix >> 8) & 255u) * rxz +
                               (double)((ix >> 16) & 255u) * txy + (double)(ix >> 24) * txz;
@@ -176,7 +190,7 @@ __global__ __launch_bounds__(256, 5) void k2_fd_fold(WsView ws, FoldArgs a, floa
             sincos_rev(frac_rev(ph), s, c);
             *reinterpret_cast<float2*>(Ac + (size_t)p * FOLD_TROW + lp * 8) = make_float2(cgr * c - cgi * s, cgr * s + cgi * c);
         }
-        wave_lds_sync();
+        fold_sync<WS>();
 
         // ---- E2' fragments (B operand, 32 columns = 16 subcarrier offsets x {re, im}); element j of K-step s is row
         // kk = 16s + 8h + j, i.e. path 8s + 4h + (j>>1), component j&1.  Column c = 0 holds (Re G, -Im G) = (cos, sin)
@@ -208,17 +222,17 @@ __global__ __launch_bounds__(256, 5) void k2_fd_fold(WsView ws, FoldArgs a, floa
         const int nb = (bn - c0) < a.ch ? (bn - c0) : a.ch;
         const bool last = a0 + nb == a.nblk;
         float* __restrict__ o = out + (size_t)ul * user_floats + (size_t)a0 * 32;
-        wave_lds_sync();                                                   // the previous chunk's tiles have read E1
+        fold_sync<WS>();                                                   // the previous chunk's tiles have read E1
         // E1[a][l] = e^{-j 2pi q_l sc(16 (a0 + a))}; q = qh + ql with qh a multiple of 2^-12, so qh * (sc mod 4096) is
         // exact in float32 and qh * (sc - sc mod 4096) is an integer (k2_channel_fd_mfma.hip gen_b_step)
-        for (int ab = hh; ab < nb; ab += 2) {
+        for (int ab = 2 * sub + hh; ab < nb; ab += 2 * WS) {
             const int sca = a.sc_first + a.sc_stride * 16 * (a0 + ab);
             const float p1 = qhf * (float)(sca & 4095);
             float s, c;
             sincos_rev(fmaf(qlf, (float)sca, p1 - rintf(p1)), s, c);
             *reinterpret_cast<float2*>(E1 + (size_t)ab * FOLD_TROW + lp * 8) = make_float2(c, -s);
         }
-        wave_lds_sync();
+        fold_sync<WS>();
 
         // ---- row tiles: 32 rows (a,p) each
         const uint32_t* rowoff = last ? rowoff1 : rowoff0;
@@ -227,7 +241,7 @@ __global__ __launch_bounds__(256, 5) void k2_fd_fold(WsView ws, FoldArgs a, floa
         const int ntiles = (rows + 31) >> 5;
         const __amdgpu_buffer_rsrc_t orsrc =
             __builtin_amdgcn_make_buffer_rsrc(o, 0, (int)((unsigned)(user_floats - (size_t)a0 * 32) * 4u), 0x00020000);
-        for (int rt = 0; rt < ntiles; ++rt) {
+        for (int rt = sub; rt < ntiles; rt += WS) {
             const uint32_t src = rowsrc[(rt << 5) + lp];
             const unsigned char* arow = Ac + (src >> 16) + hh * 32;
             const unsigned char* erow = E1 + (src & 0xFFFFu) + hh * 32;
@@ -298,28 +312,30 @@ bool fd_fold_supported(const dmx_params& prm, const WsView& ws) {
 // that still lets FOUR workgroups (16 waves) share the 160 KiB, else three.  E2' is built once per work item whatever
 // ch is, so a smaller ch costs only its loop overhead.
 static constexpr int FOLD_SUPER = 64;            // blocks per work item (1024 subcarriers)
-static int fold_chunk_blocks(int M, int nblk, int forced) {
+static int fold_chunk_blocks(int M, int nblk, int forced, int table_sets) {
     const int cand[3] = {32, 16, 8};
     if (forced > 0) return forced < nblk ? forced : nblk;
-    for (int want = 4; want >= 3; --want) {
+    for (int want = 4; want >= 2; --want) {
         for (int ch : cand) {
             const int c = ch < nblk ? ch : nblk;
             const int tab = (M * c + 31) / 32 * 32;
-            const size_t smem = fold_static_bytes(tab, M) + 4 * fold_wave_bytes(M, c);
+            const size_t smem = fold_static_bytes(tab, M) + table_sets * fold_wave_bytes(M, c);
             if (smem * want <= 160 * 1024) return c;
         }
     }
     return 8 < nblk ? 8 : nblk;
 }
 
-// Automatic choice (variant 0), from profiles/r2_fold_sweep.txt (200k users x 25 paths; ms for this kernel | the best of
-// the others: 9 small-output, 2 matrix cores, 1 fp32 vector):
+// Automatic choice (variant 0), from profiles/r2_fold_sweep.txt (25 paths; ms for this kernel | the best of the others:
+// 9 small-output, 2 matrix cores, 1 fp32 vector).  200k users:
 //    8 pairs: K=4 0.17 | 0.19 (9)   K=8 0.20 | 0.30 (9)   K=16 0.24 | 0.52 (9)   K=64 0.28 | 1.31 (1)   K=512 1.35 | 6.6 (2)
 //   32 pairs: K=8 0.35 | 0.47 (9)   K=16 0.41 | 1.16 (9)   K=64 0.76 | 2.29 (2)   K=256 2.79 | 5.2 (2)   K=512 5.7 | 7.9 (2)
-//   48 pairs: K=64 1.40 | 2.60 (2)  K=128 2.23 | 3.57 (2)  K=256 5.17 | 6.40 (2)  K=512 10.2 | 10.1 (2)
-//   64 pairs: K=8 0.76 | 1.07 (9)   K=32 1.08 | 2.24 (2)   K=64 1.57 | 2.83 (2)   K=128 3.85 | 4.14 (2)  K=256 7.97 | 7.19 (2)
-// Beyond 32 pairs the per-wave tables (Ac: 272 B per pair) cut the resident workgroups and the plain matrix-core kernel,
-// whose B' generation is then shared by two or more full row tiles, catches up from the many-subcarrier end.
+// 100k users, one table set per workgroup (33+ pairs):
+//   48 pairs: K=64 0.74 | 1.11   K=256 1.98 | 3.20   K=512 4.15 | 4.79        64 pairs: K=64 0.86 | 1.23   K=128 1.38 | 1.88
+//   64 pairs: K=256 2.83 | 3.47  K=512 5.34 | 5.07   K=1024 10.6 | 9.1        96 pairs: K=64 1.28 | 1.59   K=256 4.17 | 3.96
+//  128 pairs: K=64 1.64 | 2.57   K=256 5.48 | 4.78   K=512 10.8 | 8.6
+// This kernel levels off near 4.8-5.0 TB/s; the plain matrix-core kernel, whose B' generation is shared by M/32 full row
+// tiles, passes it from the many-subcarrier end as the panel grows.
 bool fd_fold_preferred(const dmx_params& prm, const WsView& ws) {
     const int64_t M = (int64_t)prm.ue_shape[0] * prm.ue_shape[1] * prm.bs_shape[0] * prm.bs_shape[1];
     const int K = prm.n_selected;
@@ -327,8 +343,10 @@ bool fd_fold_preferred(const dmx_params& prm, const WsView& ws) {
     // 8 pairs K=1 0.15 | 0.12 (9), K=3 0.175 | 0.170, K=4 0.17 | 0.19; 64 pairs K=1 0.64 | 0.18, K=4 0.69 | 0.54, K=8 0.76 | 1.07
     if (!fd_fold_supported(prm, ws) || K < (M <= 16 ? 4 : 6)) return false;
     if (M <= 32) return true;
-    if (M <= 48) return K <= 256;
-    return K <= 128;
+    if (M <= 48) return K <= 512;
+    if (M <= 64) return K <= 256;
+    if (M <= 96) return K <= 128;
+    return K <= 64;
 }
 
 int launch_channels_fd_fold(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count, float2* out,
@@ -354,7 +372,12 @@ int launch_channels_fd_fold(const dmx_params& prm, const WsView& ws, int64_t use
         if (env) chunk_blocks = atoi(env);
         if (chunk_blocks != 8 && chunk_blocks != 16 && chunk_blocks != 32) chunk_blocks = 0;
     }
-    a.ch = fold_chunk_blocks(a.M, a.nblk, chunk_blocks);
+    // table sets per workgroup: one per wave up to 32 pairs, one for the whole workgroup above (measurement hook
+    // DMX_FOLD_SHARED=0|1 forces either)
+    bool shared = a.M >= FOLD_SHARED_FROM;
+    if (const char* env = getenv("DMX_FOLD_SHARED")) shared = env[0] == '1';
+    const int sets = shared ? 1 : 4;
+    a.ch = fold_chunk_blocks(a.M, a.nblk, chunk_blocks, sets);
     a.sch = (FOLD_SUPER / a.ch) * a.ch;
     if (a.sch > a.nblk) a.sch = (a.nblk + a.ch - 1) / a.ch * a.ch;
     a.nsuper = (a.nblk + a.sch - 1) / a.sch;
@@ -363,10 +386,10 @@ int launch_channels_fd_fold(const dmx_params& prm, const WsView& ws, int64_t use
     a.tab_rows = (a.M * a.ch + 31) / 32 * 32;
     a.k_tail = a.K - 16 * (a.nblk - 1);
     if ((size_t)a.M * (size_t)a.K * 8 >= (size_t)1 << 30) { set_error("%d x %d outputs per user are too many for the folded kernel", a.M, a.K); return DMX_ERR_SHAPE; }
-    const size_t smem = fold_static_bytes(a.tab_rows, a.M) + 4 * fold_wave_bytes(a.M, a.ch);
+    const size_t smem = fold_static_bytes(a.tab_rows, a.M) + sets * fold_wave_bytes(a.M, a.ch);
     if (smem > 160 * 1024) { set_error("folded kernel tables of %zu bytes exceed LDS", smem); return DMX_ERR_SHAPE; }
     const int64_t items = user_count * a.nsuper;
-    const void* kfn = reinterpret_cast<const void*>(k2_fd_fold<true>);
+    const void* kfn = shared ? reinterpret_cast<const void*>(k2_fd_fold<true, 4>) : reinterpret_cast<const void*>(k2_fd_fold<true, 1>);
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
@@ -377,9 +400,10 @@ int launch_channels_fd_fold(const dmx_params& prm, const WsView& ws, int64_t use
         per_cu = 1;
     }
     int64_t grid = (int64_t)device_cu_count() * per_cu;
-    const int64_t need = (items + 3) / 4;
+    const int64_t need = shared ? items : (items + 3) / 4;
     if (grid > need) grid = need;
-    hipLaunchKernelGGL((k2_fd_fold<true>), dim3((unsigned)grid), dim3(256), smem, stream, ws, a, reinterpret_cast<float*>(out), items);
+    if (shared) hipLaunchKernelGGL((k2_fd_fold<true, 4>), dim3((unsigned)grid), dim3(256), smem, stream, ws, a, reinterpret_cast<float*>(out), items);
+    else hipLaunchKernelGGL((k2_fd_fold<true, 1>), dim3((unsigned)grid), dim3(256), smem, stream, ws, a, reinterpret_cast<float*>(out), items);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("k2_fd_fold launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
     return DMX_OK;

@@ -134,7 +134,8 @@ int dmx_path_prep(const dmx_rays* rays, const dmx_params* prm, void* workspace, 
  * variant: 0 = automatic; 1 = fp32 vector kernel; 2 = split-precision MFMA kernel (persistent workgroups of 8
  *          waves, two per CU, or of 4 waves up to 128 subcarriers; non-temporal output stores); 9 = small-output
  *          kernel (one wave per user; automatic when few subcarriers are selected); 12 = folded matrix-core kernel
- *          for at most 64 antenna pairs (needs prm->sc_stride > 0; automatic up to 32 pairs from 32 subcarriers on).
+ *          for at most 128 antenna pairs (needs prm->sc_stride > 0; automatic for every such selection up to 32 pairs and
+ *          up to 128 pairs while few subcarriers are selected).
  *          Tuning knobs kept for A/B measurements (all parity-tested): 3 = MFMA with plain stores (16 waves),
  *          4 / 5 / 10 = 4- / 8- / 16-wave workgroups whatever the subcarrier count, 8 = one 16-wave workgroup per
  *          (user, row block) instead of persistent workgroups, 11 = exactly the resident number of persistent

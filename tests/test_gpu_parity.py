@@ -57,7 +57,7 @@ def test_golden(name, variant, capsys):
     if variant == 12:
         from deepmimo_amd.engine import uniform_stride
         pairs = int(np.prod(case["bs_shape"]) * np.prod(case["ue_shape"]))
-        if not (case["freq_domain"] and not case["rx_filter"] and pairs <= 64 and uniform_stride(np.array(case["selected"]))[1] > 0):
+        if not (case["freq_domain"] and not case["rx_filter"] and pairs <= 128 and uniform_stride(np.array(case["selected"]))[1] > 0):
             pytest.skip("not a case of the folded kernel")
     dm.config("fd_kernel_variant", variant)
     try:
@@ -169,7 +169,9 @@ SHAPES_FOLD = [
     (19, 25, [8, 2], [2, 1], 512, list(range(0, 512, 2)), dict(all_valid=True, max_delay=45e-6)),   # 32 pairs, stride 2
     (17, 7, [4, 3], [1, 1], 100, list(range(100)), {}),                                 # 12 pairs (rows straddle tiles), K % 16 = 4
     (13, 32, [5, 1], [1, 1], 2048, list(range(7, 2048, 3)), dict(max_delay=95e-6)),     # 5 pairs, K = 681: several chunks + tail, first != 0
-    (9, 25, [8, 4], [2, 1], 128, list(range(128)), dict(ue_rot=[10, 20, 30])),          # 64 pairs: the kernel's upper limit
+    (9, 25, [8, 4], [2, 1], 128, list(range(128)), dict(ue_rot=[10, 20, 30])),          # 64 pairs: one table set per workgroup
+    (8, 25, [8, 8], [2, 1], 512, list(range(512)), dict(all_valid=True, max_delay=45e-6)),   # 128 pairs: the kernel's upper limit
+    (14, 9, [7, 5], [1, 1], 300, list(range(5, 305)), {}),                               # 35 pairs (odd), K % 16 = 12, shared tables
     (12, 25, [2, 1], [1, 1], 1024, list(range(1024)), dict(all_valid=True, max_delay=90e-6)),   # 2 pairs: 16 blocks per tile
     (11, 3, [8, 1], [1, 1], 64, list(range(10, 43)), {}),                               # K = 33: a lone subcarrier in the last block
     (10, 25, [1, 1], [1, 1], 4096, list(range(4096)), dict(all_valid=True, max_delay=300e-6)),  # one pair, 4096 subcarriers
@@ -179,7 +181,7 @@ SHAPES_FOLD = [
 def _fold_applicable(shape):
     n, L, bs, ue, N, sel, extra = shape
     from deepmimo_amd.engine import uniform_stride
-    return uniform_stride(np.asarray(sel))[1] > 0 and bs[0] * bs[1] * ue[0] * ue[1] <= 64
+    return uniform_stride(np.asarray(sel))[1] > 0 and bs[0] * bs[1] * ue[0] * ue[1] <= 128
 
 
 ALL_SHAPES = SHAPES + SHAPES_SMALL + SHAPES_FOLD
@@ -198,7 +200,7 @@ def test_vs_oracle_shapes(shape, variant):
     if variant == 9 and not _small_kernel_fits(shape):
         pytest.skip("one user's factor tables exceed the LDS of the small-output kernel")
     if variant == 12 and not _fold_applicable(shape):
-        pytest.skip("the folded kernel needs uniformly spaced subcarriers and at most 64 antenna pairs")
+        pytest.skip("the folded kernel needs uniformly spaced subcarriers and at most 128 antenna pairs")
     if variant in (3, 8, 10, 11) and shape not in SHAPES[2:7] + SHAPES_FOLD[3:5]:
         pytest.skip("measurement knobs are checked on a subset of the shapes")
     rays = onp.synth_rays(n, L, seed=1000 + n, all_valid=extra.get("all_valid", False),
@@ -991,8 +993,8 @@ def test_extreme_power_spread(bs, ue, K, variant):
     import deepmimo_amd as dm
     from oracle import oracle_np as onp
     n, L = 48, 25
-    if variant == 12 and bs[0] * bs[1] * ue[0] * ue[1] > 64:
-        pytest.skip("folded kernel: at most 64 antenna pairs")
+    if variant == 12 and bs[0] * bs[1] * ue[0] * ue[1] > 128:
+        pytest.skip("folded kernel: at most 128 antenna pairs")
     rays = onp.synth_rays(n, L, seed=4242, all_valid=True)
     rng = np.random.default_rng(7)
     p = rays["power"]
