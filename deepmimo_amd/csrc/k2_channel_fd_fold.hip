@@ -99,7 +99,7 @@ __device__ __forceinline__ void fold_sync() {
 // workgroup barrier anywhere); 4 - the workgroup works on one item with ONE set of tables and splits its row tiles over
 // the waves (33 ... 128 pairs: per-wave tables would leave one workgroup per CU).
 template <bool NT, int WS>
-__global__ __launch_bounds__(256, 5) void k2_fd_fold(WsView ws, FoldArgs a, float* __restrict__ out, int64_t items) {
+__global__ __launch_bounds__(256, WS == 1 ? 5 : 4) void k2_fd_fold(WsView ws, FoldArgs a, float* __restrict__ out, int64_t items) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* rowoff0 = reinterpret_cast<uint32_t*>(smem);                 // [tab_rows] byte offset of row (a,p), full chunk
     uint32_t* rowoff1 = rowoff0 + a.tab_rows;                              // [tab_rows] same for the last chunk
