@@ -45,6 +45,7 @@ WORKLOADS = {
     # DeepMIMO's default arrays (channel.py:36-46: BS 8x1, UE 1x1): the folded matrix-core kernel's regime
     "d8_default_arrays": dict(n_ue=200_000, bs=[8, 1], ue=[1, 1], L=25, N=512),
     "d16_k256": dict(n_ue=200_000, bs=[4, 4], ue=[1, 1], L=25, N=256),
+    "d64_k256": dict(n_ue=100_000, bs=[8, 8], ue=[1, 1], L=25, N=256),      # 64 pairs: the folded kernel with workgroup-shared tables
     # headline shape, but the consumer of docs/manual.ipynb cell 105 fused in: 64-beam sweep, no [N, ., K] tensor written
     "c3_beam_power": dict(n_ue=100_000, bs=[8, 8], ue=[2, 2], L=25, N=512, beams=64),
     "tiny": dict(n_ue=512, bs=[8, 8], ue=[2, 2], L=25, N=512),
@@ -381,7 +382,7 @@ def main():
                                    CARRIER_HZ if dop else 0.0)
     if rank == 0 and world == 1:
         cpu_users = args.cpu_users if args.cpu_users >= 0 else {"c3_headline": 400, "c2_asu_shape": 2000, "c4_shard": 400,
-                                                                "c5_massive": 8, "d8_default_arrays": 8000, "d16_k256": 8000,
+                                                                "c5_massive": 8, "d8_default_arrays": 8000, "d16_k256": 8000, "d64_k256": 3000,
                                                                 "c3_beam_power": 300, "tiny": 100}[args.workload]
         if cpu_users > 0:
             res["cpu_baseline"] = cpu_baseline(args.workload, 0, cpu_users, args.cpu_workers)
