@@ -48,6 +48,10 @@ WORKLOADS = {
     "d64_k256": dict(n_ue=100_000, bs=[8, 8], ue=[1, 1], L=25, N=256),      # 64 pairs: the folded kernel with workgroup-shared tables
     # headline shape, but the consumer of docs/manual.ipynb cell 105 fused in: 64-beam sweep, no [N, ., K] tensor written
     "c3_beam_power": dict(n_ue=100_000, bs=[8, 8], ue=[2, 2], L=25, N=512, beams=64),
+    # the other two output modes of the same path at the headline shape: time domain (channel.py:285-287: [N, M_rx, M_tx, L]
+    # taps, 5.1 GB) and the receive low-pass filter (ofdm.rx_filter = 1: FFT gains table + contraction; 20k users = 21 GB)
+    "c3_time_domain": dict(n_ue=100_000, bs=[8, 8], ue=[2, 2], L=25, N=512, td=True),
+    "c3_rx_filter": dict(n_ue=20_000, bs=[8, 8], ue=[2, 2], L=25, N=512, lpf=True),
     "tiny": dict(n_ue=512, bs=[8, 8], ue=[2, 2], L=25, N=512),
 }
 
@@ -82,6 +86,8 @@ def make_params(w):
     p.ofdm.subcarriers = w["N"]
     p.ofdm.selected_subcarriers = np.arange(w["N"])
     p.enable_doppler = int(bool(w.get("doppler")))
+    p.freq_domain = 0 if w.get("td") else 1
+    p.ofdm.rx_filter = int(bool(w.get("lpf")))
     p.validate(w["n_ue"])
     return p
 
@@ -93,7 +99,8 @@ def _cpu_chunk(args):
     dop = bool(w.get("doppler"))
     rays = onp.synth_rays(n, w["L"], seed=seed, all_valid=True, with_doppler=dop)
     op = onp.make_params(bs_antenna=dict(shape=w["bs"]), ue_antenna=dict(shape=w["ue"]), num_paths=w["L"],
-                         enable_doppler=int(dop), ofdm=dict(subcarriers=w["N"], selected_subcarriers=np.arange(w["N"])))
+                         enable_doppler=int(dop), freq_domain=0 if w.get("td") else 1,
+                         ofdm=dict(subcarriers=w["N"], selected_subcarriers=np.arange(w["N"]), rx_filter=int(bool(w.get("lpf")))))
     dkw = dict(doppler=dict(vel=rays["doppler_vel"], acc=rays["doppler_acc"], carrier_freq=CARRIER_HZ)) if dop else {}
     t0 = time.perf_counter()
     H = onp.compute_channels(rays, op, style="reference", **dkw)["channel"]
@@ -129,7 +136,7 @@ def cpu_baseline_here(w, sample_users, workers):
             dtw = time.perf_counter() - t0
         out["all_cores"] = {"value": per * workers / dtw, "unit": "user-channels/s", "cores": workers,
                             "sample": f"{workers} processes x {per} users, {dtw:.1f} s wall"}
-    if not w.get("beams"):
+    if not (w.get("beams") or w.get("td") or w.get("lpf")):
         out["c_port"] = c_port_baseline(w, sample_users, workers)
     return out
 
@@ -286,7 +293,11 @@ def main():
         bws = torch.empty(bws_bytes + 256, dtype=torch.uint8, device=dev)
         bws_ptr = bws.data_ptr() + (-bws.data_ptr()) % 256
     else:
-        out = torch.empty((n_ue, m_rx, m_tx, w["N"]), dtype=torch.complex64, device=dev)
+        out = torch.empty((n_ue, m_rx, m_tx, w["L"] if w.get("td") else w["N"]), dtype=torch.complex64, device=dev)
+    if w.get("lpf"):
+        lws_bytes = int(eng.lib.dmx_lpf_workspace_bytes(C.byref(p0), n_ue, prep0.n_paths_loaded))
+        lws = torch.empty(lws_bytes + 256, dtype=torch.uint8, device=dev)
+        lws_ptr = lws.data_ptr() + (-lws.data_ptr()) % 256
 
     def step(ev0=None, ev1=None):
         stream = eng._stream_ptr()
@@ -299,6 +310,12 @@ def main():
             nat.check(eng.lib.dmx_beam_power(C.byref(p0), wsp, prep0.n_ue, prep0.n_paths_loaded, 0, prep0.n_ue,
                                              C.c_void_p(cb.data_ptr()), n_beams, C.c_void_p(bws_ptr), bws_bytes,
                                              C.c_void_p(out.data_ptr()), C.c_void_p(best.data_ptr()), stream), "dmx_beam_power")
+        elif w.get("td"):
+            nat.check(eng.lib.dmx_channels_td(C.byref(p0), wsp, prep0.n_ue, prep0.n_paths_loaded, 0, prep0.n_ue,
+                                              C.c_void_p(out.data_ptr()), stream), "dmx_channels_td")
+        elif w.get("lpf"):
+            nat.check(eng.lib.dmx_channels_fd_lpf(C.byref(p0), wsp, prep0.n_ue, prep0.n_paths_loaded, 0, prep0.n_ue,
+                                                  C.c_void_p(lws_ptr), lws_bytes, C.c_void_p(out.data_ptr()), stream), "dmx_channels_fd_lpf")
         else:
             nat.check(eng.lib.dmx_channels_fd(C.byref(p0), wsp, prep0.n_ue, prep0.n_paths_loaded, 0, prep0.n_ue,
                                               C.c_void_p(out.data_ptr()), int(args.variant), stream), "dmx_channels_fd")
@@ -334,9 +351,13 @@ def main():
     step_s = elapsed / max(args.steps, 1)
     choice = int(args.variant) if args.variant else int(eng.lib.dmx_fd_kernel_choice(C.byref(p0), prep0.n_paths_loaded))
     kernel = "k2c_beam_power" if n_beams else {1: "k2_fd_valu", 2: "k2_fd_mfma", 9: "k2_fd_small", 12: "k2_fd_fold"}.get(choice, "k2_fd_mfma")
-    split = kernel in ("k2_fd_mfma", "k2_fd_fold", "k2c_beam_power")
+    if w.get("td"):
+        kernel = "k4_td"
+    if w.get("lpf"):
+        kernel = "k3_lpf_fft_wave + k2_fd_mfma (table-fed)"
+    split = kernel in ("k2_fd_mfma", "k2_fd_fold", "k2c_beam_power") or bool(w.get("lpf"))
     rows = m_rx * (n_beams if n_beams else m_tx)
-    cmacs = n_ue * rows * w["N"] * w["L"]
+    cmacs = n_ue * rows * (1 if w.get("td") else w["N"]) * w["L"]
     if n_beams:
         # compute-bound by construction (nothing of size [N, ., K] touches HBM): priced against the dense f16 MFMA peak
         # with the ALGORITHMIC flops, 8 real flops per complex MAC of the (rx, beam) x path x subcarrier contraction;
@@ -351,7 +372,8 @@ def main():
                 "executed_mfma_flops_per_launch": 2.0 * n_ue * ((rows + 31) // 32 * 32) * (2 * w["N"]) * 64 * 3,
                 "output_not_written_bytes": n_ue * 8 * rows * w["N"]}
     else:
-        bytes_per_user = 8 * m_rx * m_tx * w["N"] + 4 * w["L"] * (10 if dop else 8)
+        last = w["L"] if w.get("td") else w["N"]
+        bytes_per_user = 8 * m_rx * m_tx * last + 4 * w["L"] * (10 if dop else 8)
         achieved = n_ue * bytes_per_user / (k2_ms * 1e-3) / 1e9
         traffic, note = measured_traffic(args.workload, n_ue, args.variant)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -366,6 +388,8 @@ def main():
         "config": {"workload": f"{args.workload}: {n_ue} users/GPU x BS {w['bs'][0]}x{w['bs'][1]} ({m_tx}) x UE "
                                f"{w['ue'][0]}x{w['ue'][1]} ({m_rx}) antennas x {w['L']} paths "
                                f"({'random valid count' if args.random_valid else 'all valid'}) x {w['N']} subcarriers"
+                               + (" - TIME DOMAIN taps [N, M_rx, M_tx, L]" if w.get("td") else "")
+                               + (" - with ofdm.rx_filter = 1 (sinc low-pass)" if w.get("lpf") else "")
                                + (" + Doppler term (f_c 3.5 GHz)" if dop else "")
                                + (f" -> {n_beams}-beam sweep mean |F @ H| (no channel tensor written)" if n_beams else ""),
                    "users_total": total_users, "parallelism": f"user-shard x{world}",
@@ -382,7 +406,7 @@ def main():
                                    CARRIER_HZ if dop else 0.0)
     if rank == 0 and world == 1:
         cpu_users = args.cpu_users if args.cpu_users >= 0 else {"c3_headline": 400, "c2_asu_shape": 2000, "c4_shard": 400,
-                                                                "c5_massive": 8, "d8_default_arrays": 8000, "d16_k256": 8000, "d64_k256": 3000,
+                                                                "c5_massive": 8, "d8_default_arrays": 8000, "d16_k256": 8000, "d64_k256": 3000, "c3_time_domain": 20000, "c3_rx_filter": 200,
                                                                 "c3_beam_power": 300, "tiny": 100}[args.workload]
         if cpu_users > 0:
             res["cpu_baseline"] = cpu_baseline(args.workload, 0, cpu_users, args.cpu_workers)
