@@ -49,9 +49,9 @@ WORKLOADS = {
     # headline shape, but the consumer of docs/manual.ipynb cell 105 fused in: 64-beam sweep, no [N, ., K] tensor written
     "c3_beam_power": dict(n_ue=100_000, bs=[8, 8], ue=[2, 2], L=25, N=512, beams=64),
     # the other two output modes of the same path at the headline shape: time domain (channel.py:285-287: [N, M_rx, M_tx, L]
-    # taps, 5.1 GB) and the receive low-pass filter (ofdm.rx_filter = 1: FFT gains table + contraction; 20k users = 21 GB)
+    # taps, 5.1 GB) and the receive low-pass filter (ofdm.rx_filter = 1: FFT gains table + contraction; the headline shape: 105 GB of output + a 10 GB gains table)
     "c3_time_domain": dict(n_ue=100_000, bs=[8, 8], ue=[2, 2], L=25, N=512, td=True),
-    "c3_rx_filter": dict(n_ue=20_000, bs=[8, 8], ue=[2, 2], L=25, N=512, lpf=True),
+    "c3_rx_filter": dict(n_ue=100_000, bs=[8, 8], ue=[2, 2], L=25, N=512, lpf=True),
     "tiny": dict(n_ue=512, bs=[8, 8], ue=[2, 2], L=25, N=512),
 }
 
@@ -179,7 +179,10 @@ def cpu_baseline(workload, users_override, sample_users, workers):
            "--cpu-users", str(sample_users), "--cpu-workers", str(workers)]
     if users_override:
         cmd += ["--users", str(users_override)]
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    # one BLAS / OpenMP thread per process: "cores" then is what it says (only the rx_filter oracle calls BLAS at all, and
+    # 16 worker processes x 256 BLAS threads each is how that leg once took a minute)
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
     if r.returncode != 0:
         raise RuntimeError("cpu baseline failed:\n" + r.stderr[-2000:])
     return json.loads(r.stdout.strip().splitlines()[-1])

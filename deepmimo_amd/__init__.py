@@ -18,8 +18,9 @@ from .channel import ChannelGenParameters
 from .dataset import Dataset, MacroDataset
 from .geometry import steering_vec
 from .core import generate, load
+from .generator_utils import get_idxs_with_limits, LinearPath
 
 __version__ = consts.VERSION
 
 __all__ = ["generate", "load", "Dataset", "MacroDataset", "ChannelGenParameters", "config", "steering_vec",
-           "DotDict", "consts"]
+           "get_idxs_with_limits", "LinearPath", "DotDict", "consts"]

@@ -42,6 +42,7 @@ DIST_PARAM_NAME = "distance"
 N_UE_PARAM_NAME = "n_ue"
 INTER_INT_PARAM_NAME = "inter_int"
 NUM_INTERACTIONS_PARAM_NAME = "num_interactions"
+INTER_STR_PARAM_NAME = "inter_str"
 
 AOA_AZ_ROT_PARAM_NAME = "_aoa_az_rot"
 AOA_EL_ROT_PARAM_NAME = "_aoa_el_rot"

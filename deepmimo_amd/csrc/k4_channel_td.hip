@@ -8,6 +8,7 @@
 // per table entry instead of one per output element) and multiplies them out; k4_td is the table-free form
 // for panels whose tables exceed LDS.
 #include "dmx_common.h"
+#include <stdlib.h>
 
 namespace dmx {
 
@@ -42,6 +43,7 @@ __global__ __launch_bounds__(256) void k4_td(WsView ws, TdArgs a, float2* __rest
     }
 }
 
+template <bool PAIRS>
 __global__ __launch_bounds__(256) void k4_td_tab(WsView ws, TdArgs a, float2* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int P = ws.P;
@@ -70,23 +72,38 @@ __global__ __launch_bounds__(256) void k4_td_tab(WsView ws, TdArgs a, float2* __
         brx[i] = v;                                         // the two tables are contiguous
     }
     __syncthreads();
-    // thread = output element, 256 apart per step; (slot s, transmit element m, receive element r) of element i are
-    // advanced incrementally - three 64-bit divisions per element were most of this kernel's instructions
+    // thread = PAIR of consecutive output elements, 512 elements apart per step (16-byte non-temporal stores: a wave writes
+    // 1 KiB per instruction); (slot s, transmit element m, receive element r) of the pair's first element are advanced
+    // incrementally - three 64-bit divisions per element were most of this kernel's instructions.  PAIRS needs an even
+    // element count per user (16-byte aligned user blocks); otherwise one element per thread, 256 apart.
+    constexpr unsigned STEP = PAIRS ? 512u : 256u;
     const unsigned tid = threadIdx.x;
-    unsigned sidx = tid % (unsigned)P, q = tid / (unsigned)P;               // q = r * m_tx + m
-    unsigned m = q % (unsigned)a.m_tx, r = q / (unsigned)a.m_tx;
-    const unsigned ds = 256u % (unsigned)P, dq = 256u / (unsigned)P;
-    const unsigned dm = dq % (unsigned)a.m_tx, dr = dq / (unsigned)a.m_tx;
-    for (size_t i = tid; i < per_user; i += 256) {
-        const float2 b = brx[r * P + sidx], t = atx[m * P + sidx];
-        o[i] = make_float2(b.x * t.x - b.y * t.y, b.x * t.y + b.y * t.x);
+    const unsigned e0 = PAIRS ? 2u * tid : tid;
+    const unsigned uP = (unsigned)P, uT = (unsigned)a.m_tx;
+    unsigned sidx = e0 % uP, q = e0 / uP;                                   // q = r * m_tx + m
+    unsigned m = q % uT, r = q / uT;
+    const unsigned ds = STEP % uP, dq = STEP / uP;
+    const unsigned dm = dq % uT, dr = dq / uT;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    for (size_t i = e0; i < per_user; i += STEP) {
+        const float2 b = brx[r * uP + sidx], t = atx[m * uP + sidx];
+        const float2 v0 = make_float2(b.x * t.x - b.y * t.y, b.x * t.y + b.y * t.x);
+        if (PAIRS) {
+            unsigned s1 = sidx + 1, m1 = m, r1 = r;
+            if (s1 == uP) { s1 = 0; if (++m1 == uT) { m1 = 0; ++r1; } }
+            const float2 b1 = brx[r1 * uP + s1], t1 = atx[m1 * uP + s1];    // i + 1 < per_user: per_user is even
+            f4v w = {v0.x, v0.y, b1.x * t1.x - b1.y * t1.y, b1.x * t1.y + b1.y * t1.x};
+            __builtin_nontemporal_store(w, reinterpret_cast<f4v*>(o + i));
+        } else {
+            o[i] = v0;
+        }
         sidx += ds;
         unsigned carry = 0;
-        if (sidx >= (unsigned)P) { sidx -= (unsigned)P; carry = 1; }
+        if (sidx >= uP) { sidx -= uP; carry = 1; }
         m += dm + carry;
         r += dr;
-        if (m >= (unsigned)a.m_tx) { m -= (unsigned)a.m_tx; ++r; }
-        if (m >= (unsigned)a.m_tx) { m -= (unsigned)a.m_tx; ++r; }       // dm + carry can reach m_tx
+        if (m >= uT) { m -= uT; ++r; }
+        if (m >= uT) { m -= uT; ++r; }                                      // dm + carry can reach m_tx
     }
 }
 
@@ -100,8 +117,11 @@ int launch_channels_td(const dmx_params& prm, const WsView& ws, int64_t user_beg
     a.ue_mh = prm.ue_shape[0];
     a.bs_mh = prm.bs_shape[0];
     const size_t smem = (size_t)(a.m_rx + a.m_tx) * ws.P * 8;
-    if (smem <= 64 * 1024)
-        hipLaunchKernelGGL(k4_td_tab, dim3((unsigned)user_count), dim3(256), smem, stream, ws, a, out);
+    const bool pairs = ((size_t)a.m_rx * a.m_tx * ws.P) % 2 == 0 && ((uintptr_t)out % 16) == 0 && getenv("DMX_TD_NARROW") == nullptr;   // env = measurement hook: 8-byte stores
+    if (smem <= 64 * 1024 && pairs)
+        hipLaunchKernelGGL(k4_td_tab<true>, dim3((unsigned)user_count), dim3(256), smem, stream, ws, a, out);
+    else if (smem <= 64 * 1024)
+        hipLaunchKernelGGL(k4_td_tab<false>, dim3((unsigned)user_count), dim3(256), smem, stream, ws, a, out);
     else
         hipLaunchKernelGGL(k4_td, dim3((unsigned)user_count), dim3(256), 0, stream, ws, a, out);
     hipError_t e = hipGetLastError();

@@ -420,12 +420,76 @@ class Dataset(DotDict):
         return np.linalg.norm(self.rx_pos - self.tx_pos, axis=1)             # dataset.py:661-663
 
     def _compute_inter_int(self) -> np.ndarray:
+        v = np.array(self._inter_host(), copy=True)                          # dataset.py:629-637
+        v[np.isnan(v)] = -1
+        return v.astype(int)
+
+    def _inter_host(self) -> np.ndarray:
         inter = self.inter
         if hasattr(inter, "detach"):                                         # device-resident rays (load(device=...))
             inter = inter.detach().cpu().numpy()
-        v = np.array(inter, copy=True)                                       # dataset.py:629-637
-        v[np.isnan(v)] = -1
-        return v.astype(int)
+        return np.asarray(inter)
+
+    def _compute_num_interactions(self) -> np.ndarray:
+        """Bounces per path = decimal digits of the interaction code; 0 for LoS (code 0), NaN where there is no path
+        (dataset.py:621-627)."""
+        inter = self._inter_host()
+        n = np.zeros_like(inter)
+        n[np.isnan(inter)] = np.nan
+        pos = inter > 0
+        n[pos] = np.floor(np.log10(inter[pos])) + 1
+        return n
+
+    _INTER_LETTERS = {"0": "", "1": "R", "2": "D", "3": "S", "4": "T"}
+
+    def _compute_inter_str(self) -> np.ndarray:
+        """Interaction codes as letter strings: 1 reflection 'R', 2 diffraction 'D', 3 scattering 'S', 4 transmission
+        'T'; LoS (0) is '', no path is 'n' (dataset.py:639-655: the code's float text without its '.0', digit by digit)."""
+        inter = self._inter_host()
+        table = str.maketrans(self._INTER_LETTERS)
+        codes, inverse = np.unique(inter.astype(str), return_inverse=True)      # few distinct codes: translate each once
+        words = np.array(["n" if s == "nan" else s[:-2].translate(table) for s in codes.tolist()])
+        return words[inverse].reshape(inter.shape)
+
+    # -------------------------------------------------------------- user grid and index helpers (dataset.py:702-795)
+    def _compute_grid_info(self) -> Dict[str, np.ndarray]:
+        """Distinct x / y receiver coordinates -> grid_size [nx, ny] and the mean spacing along each axis."""
+        pos = np.asarray(self.rx_pos)
+        xs, ys = np.unique(pos[:, 0]), np.unique(pos[:, 1])
+        return {"grid_size": np.array([len(xs), len(ys)]),
+                "grid_spacing": np.array([np.mean(np.diff(xs)), np.mean(np.diff(ys))])}
+
+    def _is_valid_grid(self) -> bool:
+        return np.prod(self.grid_size) == self.n_ue
+
+    def subset(self, idxs) -> "Dataset":
+        """New Dataset of the selected users (dataset.py:739-773): shared objects (scene, materials, load / ray-tracing
+        parameters) by reference, every public array whose first axis is the user axis indexed by `idxs`, everything
+        else as is; private (cached per-path) entries are dropped and recomputed on demand.  Device-resident rays stay
+        on the device."""
+        n_ue = self.n_ue
+        init = {k: self._host(k) for k in SHARED_PARAMS if k in self._data}
+        init[c.N_UE_PARAM_NAME] = len(idxs)
+        out = Dataset(init)
+        for key, value in self.to_dict().items():
+            if key.startswith("_") or key in init:
+                continue
+            if isinstance(value, np.ndarray) and value.ndim > 0 and value.shape[0] == n_ue:
+                value = value[idxs]
+            elif hasattr(value, "detach") and value.dim() > 0 and value.shape[0] == n_ue:
+                import torch
+                value = value[torch.as_tensor(np.asarray(idxs), device=value.device)]
+            out[key] = value
+        return out
+
+    def get_active_idxs(self) -> np.ndarray:
+        """Users with at least one path (dataset.py:775-781)."""
+        return np.where(self.num_paths > 0)[0]
+
+    def get_uniform_idxs(self, steps) -> np.ndarray:
+        """Every steps[0]-th column and steps[1]-th row of the user grid (dataset.py:783-795)."""
+        from .generator_utils import get_uniform_idxs
+        return get_uniform_idxs(self.n_ue, self.grid_size, steps)
 
     # -------------------------------------------------------------- field of view (dataset.py:423-448)
     def apply_fov(self, bs_fov: np.ndarray = np.array([360, 180]), ue_fov: np.ndarray = np.array([360, 180])) -> None:
@@ -482,6 +546,10 @@ class Dataset(DotDict):
         c.AOD_AZ_FOV_PARAM_NAME: "_compute_fov",
         c.AOD_EL_FOV_PARAM_NAME: "_compute_fov",
         c.PWR_LINEAR_ANT_GAIN_PARAM_NAME: "_compute_power_linear_ant_gain",
+        c.NUM_INTERACTIONS_PARAM_NAME: "_compute_num_interactions",
+        "grid_size": "_compute_grid_info",
+        "grid_spacing": "_compute_grid_info",
+        c.INTER_STR_PARAM_NAME: "_compute_inter_str",
         c.INTER_INT_PARAM_NAME: "_compute_inter_int",
     }
 

@@ -715,6 +715,43 @@ def test_only_radiation_pattern_changes_reference_golden():
         dm.config("strict_reference_cache", False)
 
 
+def test_subset_and_active_users_reference_golden():
+    """`dataset.subset(dataset.get_uniform_idxs(...))` then `compute_channels`, and `get_active_idxs`, against the REAL
+    reference on the same rays (tests/golden/aux_helpers.npz from oracle/gen_helpers_golden.py; dataset.py:739-795):
+    the public entries that travel, their user-axis indexing, and the channels / LoS / pathloss of the subset."""
+    import deepmimo_amd as dm
+    z = _aux("aux_helpers.npz")
+    rays = {k[4:]: z[k] for k in z.files if k.startswith("ray_")}
+    shared = {dm.consts.SCENE_PARAM_NAME: "scene-object", dm.consts.MATERIALS_PARAM_NAME: "materials-object",
+              dm.consts.LOAD_PARAMS_PARAM_NAME: {"max_paths": 7}, dm.consts.RT_PARAMS_PARAM_NAME: {"frequency": 3.5e9}}
+    ds = dm.Dataset({**{k: v.copy() for k, v in rays.items()}, **shared})
+    assert np.array_equal(ds.get_active_idxs(), z["active"])
+    _ = (ds.grid_size, ds.num_interactions, ds.inter_int, ds.inter_str, ds.distance, ds.los, ds.pathloss)   # as the generator did
+    idxs = ds.get_uniform_idxs([3, 2])
+    assert np.array_equal(idxs, z["subset_idxs"])
+    sub = ds.subset(idxs)
+    keys = sorted(k for k in sub.keys() if not k.startswith("_") and k not in ("channel", "ch_params"))
+    assert keys == [str(k) for k in z["subset_keys"]]
+    assert sub.n_ue == int(z["subset_n_ue"]) and sub.scene == "scene-object" and sub.rt_params is ds.rt_params
+    assert np.array_equal(sub.los, z["subset_los"]) and np.array_equal(sub.rx_pos, z["subset_rx_pos"])
+    want = z["subset_pathloss"]
+    assert np.array_equal(np.isnan(sub.pathloss), np.isnan(want))
+    np.testing.assert_allclose(sub.pathloss[~np.isnan(want)], want[~np.isnan(want)], rtol=0, atol=2e-4)      # dB
+    p = dm.ChannelGenParameters()
+    p.bs_antenna.shape = np.array([4, 2])
+    p.ofdm.subcarriers = 64
+    p.ofdm.selected_subcarriers = np.arange(0, 64, 8)
+    assert_channel_close(sub.compute_channels(p), z["subset_channel"], what="subset channels vs reference")
+    assert np.array_equal(sub.num_paths, ds.num_paths[idxs])
+    # device-resident rays stay on the device through subset()
+    import torch
+    dev = torch.device("cuda", 0)
+    dds = dm.Dataset({k: (torch.from_numpy(v).to(dev) if k in dm.consts.RAY_FIELDS else v.copy()) for k, v in rays.items()})
+    dsub = dds.subset(idxs)
+    assert dsub.power.is_cuda and dsub.power.shape[0] == len(idxs)
+    assert_channel_close(dsub.compute_channels(p), z["subset_channel"], what="device-resident subset vs reference")
+
+
 def test_steering_codebook_reference_golden():
     """dm.steering_vec against the reference's vectors (tests/golden/aux_steering.npz, geometry.py:322-339), and a
     codebook of those REFERENCE vectors through the fused beam-space kernel against F @ H of the oracle."""

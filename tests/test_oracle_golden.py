@@ -191,7 +191,7 @@ def test_batch_forms_equal_scalar_forms():
 
 
 # ---- the committed recipes must keep running (crosscheck_reference.py had rotted unnoticed) -------------
-ORACLE_SCRIPTS = ("gen_golden", "gen_p2m_golden", "gen_sequence_golden", "gen_aux_golden", "crosscheck_reference",
+ORACLE_SCRIPTS = ("gen_golden", "gen_p2m_golden", "gen_sequence_golden", "gen_aux_golden", "gen_helpers_golden", "crosscheck_reference",
                   "certify_baseline", "oracle_np", "oracle_c")
 REFERENCE = "/root/reference"
 
@@ -231,20 +231,21 @@ def test_aux_goldens_regenerate_bit_identically(tmp_path):
     import shutil
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     gold = os.path.join(root, "tests", "golden")
-    names = ["aux_steering.npz", "aux_pathloss.npz", "aux_sionna.npz", "aux_stale_cache.npz"]
-    keep = {n: dict(np.load(os.path.join(gold, n))) for n in names}
+    names = ["aux_steering.npz", "aux_pathloss.npz", "aux_sionna.npz", "aux_stale_cache.npz", "aux_helpers.npz"]
+    keep = {n: dict(np.load(os.path.join(gold, n), allow_pickle=False)) for n in names}
     backup = tmp_path / "backup"
     backup.mkdir()
     for n in names:
         shutil.copy(os.path.join(gold, n), backup / n)
     try:
-        r = _run_recipe("gen_aux_golden.py")
-        assert r.returncode == 0, r.stdout[-2000:]
+        for script in ("gen_aux_golden.py", "gen_helpers_golden.py"):
+            r = _run_recipe(script)
+            assert r.returncode == 0, r.stdout[-2000:]
         for n in names:
             new = np.load(os.path.join(gold, n))
             assert sorted(new.files) == sorted(keep[n])
             for k in new.files:
-                assert np.array_equal(new[k], keep[n][k], equal_nan=True), (n, k)
+                assert np.array_equal(new[k], keep[n][k], equal_nan=new[k].dtype.kind in "fc"), (n, k)
     finally:
         for n in names:                                            # leave the committed bytes untouched
             shutil.copy(backup / n, os.path.join(gold, n))

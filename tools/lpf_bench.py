@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--users", type=int, default=20000)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--workload", default="c3_headline")
+    ap.add_argument("--quick", action="store_true", help="skip the plain path and the round-1 FFT")
     args = ap.parse_args()
     w = dict(bench.WORKLOADS[args.workload])
     w["n_ue"] = args.users
@@ -31,8 +32,9 @@ def main():
     out = torch.empty((w["n_ue"], m_rx, m_tx, w["N"]), dtype=torch.complex64, device=dev)
     out_bytes = out.numel() * 8
     res = {}
-    for label, lpf, old in (("plain (rx_filter = 0)", 0, "0"), ("rx_filter = 1, wave-per-path radix-8 FFT", 1, "0"),
-                            ("rx_filter = 1, workgroup-per-user radix-2 FFT (round 1)", 1, "1")):
+    cases = (("plain (rx_filter = 0)", 0, "0"), ("rx_filter = 1, wave-per-path radix-8 FFT", 1, "0"),
+             ("rx_filter = 1, workgroup-per-user radix-2 FFT (round 1)", 1, "1"))
+    for label, lpf, old in (cases[1:2] if args.quick else cases):
         os.environ["DMX_LPF_OLD_FFT"] = old
         p = bench.make_params(w)
         p.ofdm.rx_filter = lpf
