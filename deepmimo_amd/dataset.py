@@ -290,11 +290,11 @@ class Dataset(DotDict):
             last = len(np.atleast_1d(ofdm_[c.PARAMSET_OFDM_SC_SAMP])) if params[c.PARAMSET_FD_CH] else int(params[c.PARAMSET_NUM_PATHS])
             self._guard_host_copy(8 * int(self.n_ue) * n_ant[0] * n_ant[1] * last)
         eng, prep = self._run_prep(want_side="light")
-        chan = eng.channels(prep, variant=int(config.get("fd_kernel_variant", 0)))
+        variant = int(config.get("fd_kernel_variant", 0))
+        out = eng.channels_to_host(prep, variant=variant) if to_host else eng.channels(prep, variant=variant)
         ofdm = params[c.PARAMSET_OFDM]
         if params[c.PARAMSET_FD_CH]:
             self._warn_symbol_duration(eng.max_delay(prep), ofdm)
-        out = chan.cpu().numpy() if to_host else chan
         self[c.CHANNEL_PARAM_NAME] = out
         return out
 
@@ -323,8 +323,10 @@ class Dataset(DotDict):
         self.set_channel_params(params)
         np.random.seed(1001)
         eng, prep = self._run_prep(want_side="light")
-        y = eng.channels(prep, tx_codebook=codebook)
-        return y if config.get("channel_output", "numpy") == "torch" else y.cpu().numpy()
+        if config.get("channel_output", "numpy") == "torch":
+            return eng.channels(prep, tx_codebook=codebook)
+        cb = codebook if hasattr(codebook, "shape") else np.asarray(codebook)
+        return eng.channels_to_host(prep, tx_codebook=cb)
 
     def compute_beam_power(self, codebook, params: Optional[ChannelGenParameters] = None, return_best: bool = False):
         """Received power per beam of a TX codebook [n_beams, M_tx] - the beam sweep of docs/manual.ipynb cells

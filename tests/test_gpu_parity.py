@@ -715,6 +715,43 @@ def test_only_radiation_pattern_changes_reference_golden():
         dm.config("strict_reference_cache", False)
 
 
+@pytest.mark.parametrize("mode", ["fd", "td", "lpf", "beams"])
+def test_numpy_output_pipeline_equals_resident_tensor(mode):
+    """The default NumPy return value comes through the chunked generate -> PCIe -> host-copy pipeline
+    (ChannelEngine.channels_to_host); it must hold exactly the bits of the HBM-resident tensor, for every stage-2
+    entry point, with a ragged last chunk and more chunks than pipeline stages."""
+    import deepmimo_amd as dm
+    from deepmimo_amd.dataset import _engine
+    from oracle.oracle_np import synth_rays
+    rays = synth_rays(1037, 9, seed=4242)
+    p = dm.ChannelGenParameters()
+    p.bs_antenna.shape, p.ue_antenna.shape = np.array([4, 2]), np.array([2, 1])
+    p.ofdm.subcarriers = 64
+    p.ofdm.selected_subcarriers = np.arange(0, 64, 2)
+    if mode == "td":
+        p.freq_domain = 0
+    if mode == "lpf":
+        p.ofdm.rx_filter = 1
+    F = np.stack([dm.steering_vec(np.array([4, 2]), phi=a).ravel() for a in (-40.0, 0.0, 25.0)]) if mode == "beams" else None
+    eng = _engine()
+    old = eng.HOST_CHUNK_BYTES
+    try:
+        dm.config("channel_output", "torch")
+        ds = dm.Dataset({k: v.copy() for k, v in rays.items()})
+        want = (ds.compute_beam_channels(F, p) if mode == "beams" else ds.compute_channels(p)).cpu().numpy()
+        dm.config("channel_output", "numpy")
+        eng.HOST_CHUNK_BYTES = 100 * int(np.prod(want.shape[1:])) * 8          # 100 users per chunk: 11 chunks, 37 in the last
+        ds2 = dm.Dataset({k: v.copy() for k, v in rays.items()})
+        got = ds2.compute_beam_channels(F, p) if mode == "beams" else ds2.compute_channels(p)
+        assert isinstance(got, np.ndarray) and got.dtype == np.complex64 and got.shape == want.shape
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        got2 = ds2.compute_beam_channels(F, p) if mode == "beams" else ds2.compute_channels(p)   # staging buffers reused
+        assert np.array_equal(got2.view(np.uint32), want.view(np.uint32))
+    finally:
+        eng.HOST_CHUNK_BYTES = old
+        dm.config.reset()
+
+
 def test_subset_and_active_users_reference_golden():
     """`dataset.subset(dataset.get_uniform_idxs(...))` then `compute_channels`, and `get_active_idxs`, against the REAL
     reference on the same rays (tests/golden/aux_helpers.npz from oracle/gen_helpers_golden.py; dataset.py:739-795):
