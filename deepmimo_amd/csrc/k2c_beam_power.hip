@@ -20,13 +20,16 @@
 // K-step of one wide strip of chunk c + 1, then runs its tile against chunk c - one barrier per chunk; with fewer than
 // eight row tiles the waves split the chunk's wide strips among themselves.
 #include "k2_mfma_frag.h"
+#include <stdlib.h>
 
 namespace dmx {
 
-static constexpr int BP_WAVES = 8;
 static constexpr int BP_SLOT = 16 * 1024;       // one wide strip: 4 K-steps x {re hi, re lo, im hi, im lo} x 64 lanes x 16 B
-static constexpr int BP_CHUNK = 2;              // wide strips per chunk (8 waves x one K-step of one wide strip)
 static constexpr int BP_BUFS = 2;               // chunk buffers: generation of chunk c + 1 beside the products of chunk c
+// A workgroup of NW waves owns 32 * NW rows and works through chunks of NW / 4 wide strips (every wave generates one
+// K-step of one wide strip).  NW = 8: 2 workgroups per CU, their 4 + 4 waves per SIMD run in two lockstep groups;
+// NW = 4: 4 workgroups per CU, every SIMD holds one wave of each - four independent phases, so one workgroup's
+// generation / |Y| epilogue overlaps the others' matrix-core work (the B' fragments are generated once per 128 rows then).
 
 struct BeamPowArgs {
     int64_t user_begin;
@@ -41,12 +44,14 @@ struct BeamPowArgs {
     int32_t* best;           // [user_count] argmax_b (first maximum), -1 without paths; may be nullptr
 };
 
-__host__ __device__ inline size_t beam_pow_lds_bytes(int M) {
-    const size_t nblk = ((size_t)M + MAX_ROWS - 1) / MAX_ROWS;                 // per row block: 8 waves x 32 partial row sums
-    return (size_t)BP_BUFS * BP_CHUNK * BP_SLOT + LPAD * (8 + 4 + 4) + 16 + nblk * BP_WAVES * 32 * 4;
+__host__ __device__ inline size_t beam_pow_lds_bytes(int M, int NW) {
+    const size_t nblk = ((size_t)M + 32 * NW - 1) / (32 * NW);                 // per row block: NW waves x 32 partial row sums
+    return (size_t)BP_BUFS * (NW / 4) * BP_SLOT + LPAD * (8 + 4 + 4) + 16 + nblk * NW * 32 * 4;
 }
 
-__global__ __launch_bounds__(BP_WAVES * 64, 4) void k2c_beam_power(WsView ws, BeamPowArgs a, int64_t user_count) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 4) void k2c_beam_power(WsView ws, BeamPowArgs a, int64_t user_count) {
+    constexpr int BP_WAVES = NW, BP_CHUNK = NW / 4, MAX_ROWS = 32 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* bbuf = smem;                                                      // [BP_BUFS][BP_CHUNK][BP_SLOT]
     float* bbuf_f = reinterpret_cast<float*>(smem);
@@ -132,9 +137,10 @@ __global__ __launch_bounds__(BP_WAVES * 64, 4) void k2c_beam_power(WsView ws, Be
                     }
                 }
             }
-            float rowsum[16];
+            typedef float pv2 __attribute__((ext_vector_type(2)));   // packed fp32: one v_pk_* instruction per two rows
+            pv2 rowsum[8];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) rowsum[i] = 0.f;
+            for (int i = 0; i < 8; ++i) rowsum[i] = pv2{0.f, 0.f};
 
             // Two buffers of BP_CHUNK wide strips: every wave first generates its share of chunk c + 1 (one K-step of
             // one wide strip: lane = (subcarrier, path group)), then runs its tile against chunk c - generation and
@@ -197,8 +203,14 @@ __global__ __launch_bounds__(BP_WAVES * 64, 4) void k2c_beam_power(WsView ws, Be
                             }
                         }
                         // |Y| of this lane's subcarrier for the 16 rows it holds: both parts are in this lane
+                        // (vector instructions add to the matrix-core time on this chip, square roots do not:
+                        // profiles/r2_mfma_valu_overlap.txt - hence packed mul / fma / add around two v_sqrt_f32)
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) rowsum[i] += __builtin_amdgcn_sqrtf(fmaf(are[i], are[i], aim[i] * aim[i]));
+                        for (int i = 0; i < 8; ++i) {
+                            const pv2 re = {are[2 * i], are[2 * i + 1]}, im = {aim[2 * i], aim[2 * i + 1]};
+                            const pv2 p = __builtin_elementwise_fma(re, re, im * im);
+                            rowsum[i] += pv2{__builtin_amdgcn_sqrtf(p.x), __builtin_amdgcn_sqrtf(p.y)};
+                        }
                     }
                 }
                 __syncthreads();                       // chunk c + 1 is complete; chunk c's buffer may be overwritten
@@ -206,7 +218,7 @@ __global__ __launch_bounds__(BP_WAVES * 64, 4) void k2c_beam_power(WsView ws, Be
             if (active) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    float v = rowsum[i];
+                    float v = (i & 1) ? rowsum[i >> 1].y : rowsum[i >> 1].x;
                     for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
                     if (col == 0) rs[((blk * BP_WAVES + wave) << 5) + (i & 3) + 8 * (i >> 2) + 4 * hh] = v;
                 }
@@ -260,13 +272,15 @@ int launch_beam_power(const dmx_params& prm, const WsView& ws, int64_t user_begi
     a.fexp = t.fexp;
     a.out = out_amp;
     a.best = out_best;
-    const size_t smem = beam_pow_lds_bytes(a.M);
+    int nw = 8;
+    if (const char* env = getenv("DMX_BEAM_WAVES")) nw = atoi(env) == 4 ? 4 : 8;      // measurement hook
+    const size_t smem = beam_pow_lds_bytes(a.M, nw);
     if (smem > 160 * 1024) { set_error("%d x %d (rx, beam) rows are too many for the beam-power kernel", a.m_rx, n_beams); return DMX_ERR_SHAPE; }
-    const void* kfn = reinterpret_cast<const void*>(k2c_beam_power);
+    const void* kfn = nw == 4 ? reinterpret_cast<const void*>(k2c_beam_power<4>) : reinterpret_cast<const void*>(k2c_beam_power<8>);
     hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, BP_WAVES * 64, smem) != hipSuccess || per_cu < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, nw * 64, smem) != hipSuccess || per_cu < 1) {
         (void)hipGetLastError();
         per_cu = 1;
     }
@@ -275,7 +289,8 @@ int launch_beam_power(const dmx_params& prm, const WsView& ws, int64_t user_begi
     const int64_t g4 = user_count / 4;
     if (g4 > grid) grid = g4 < 4 * grid ? g4 : 4 * grid;
     if (grid > user_count) grid = user_count;
-    hipLaunchKernelGGL(k2c_beam_power, dim3((unsigned)grid), dim3(BP_WAVES * 64), smem, stream, ws, a, user_count);
+    if (nw == 4) hipLaunchKernelGGL(k2c_beam_power<4>, dim3((unsigned)grid), dim3(256), smem, stream, ws, a, user_count);
+    else hipLaunchKernelGGL(k2c_beam_power<8>, dim3((unsigned)grid), dim3(512), smem, stream, ws, a, user_count);
     e = hipGetLastError();
     if (e != hipSuccess) { set_error("k2c_beam_power launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
     return DMX_OK;
