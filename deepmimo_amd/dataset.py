@@ -312,7 +312,7 @@ class Dataset(DotDict):
         variant = int(config.get("fd_kernel_variant", 0))
         for b in range(0, n, max(1, int(chunk_users))):
             cnt = min(int(chunk_users), n - b)
-            yield b, eng.channels(prep, user_begin=b, user_count=cnt, variant=variant).cpu().numpy()
+            yield b, eng.channels_to_host(prep, variant=variant, user_begin=b, user_count=cnt)
 
     def compute_beam_channels(self, codebook, params: Optional[ChannelGenParameters] = None):
         """Beam-space channels ``codebook @ H`` for a TX codebook [n_beams, M_tx] (rows e.g. from

@@ -317,14 +317,17 @@ class ChannelEngine:
     HOST_CHUNK_BYTES = 256 << 20          # per pipeline stage; two device buffers + two pinned staging buffers of this size
     HOST_COPY_THREADS = 8                 # np.copyto releases the GIL; one thread moves ~12 GB/s, PCIe Gen5 ~57 GB/s
 
-    def channels_to_host(self, prep: PrepResult, variant: int = 0, tx_codebook=None, chunk_bytes: Optional[int] = None) -> np.ndarray:
+    def channels_to_host(self, prep: PrepResult, variant: int = 0, tx_codebook=None, chunk_bytes: Optional[int] = None,
+                         user_begin: int = 0, user_count: Optional[int] = None) -> np.ndarray:
         """Stage 2 straight into a NumPy array (what ``Dataset.compute_channels`` returns by default, as the reference
         does) as a three-stage pipeline over user chunks: the kernels of chunk c + 1 run on the current stream while
         chunk c crosses PCIe into one of two pinned staging buffers on a copy stream and chunk c - 1 is moved from the
         other staging buffer into the result by a few host threads (the first touch of the result's pages happens
         there too).  47 GB/s on the pool's boxes against 14 GB/s for ``tensor.cpu().numpy()``
         (tools/host_copy_probe.py), and the device never holds more than two chunks of the tensor."""
-        shape = self.channel_shape(prep)
+        if user_count is None:
+            user_count = prep.n_ue - user_begin
+        shape = self.channel_shape(prep, user_count)
         if tx_codebook is not None:
             shape = (shape[0], shape[1], int(tx_codebook.shape[0]), shape[3])
         n, per_user = shape[0], int(np.prod(shape[1:]))
@@ -335,7 +338,7 @@ class ChannelEngine:
         chunk_bytes = int(chunk_bytes or self.HOST_CHUNK_BYTES)
         cu = max(1, chunk_bytes // (per_user * 8))
         if cu >= n:                                               # one chunk: nothing to overlap
-            return self.channels(prep, variant=variant, tx_codebook=tx_codebook).cpu().numpy()
+            return self.channels(prep, user_begin=user_begin, user_count=n, variant=variant, tx_codebook=tx_codebook).cpu().numpy()
         result = np.empty(shape, dtype=np.complex64)
         flat = result.reshape(n, per_user)
         stage = self._host_stage(cu * per_user)
@@ -358,7 +361,7 @@ class ChannelEngine:
         for ci, b in enumerate(range(0, n, cu)):
             i, cnt = ci & 1, min(cu, n - b)
             # dev[i] / stage[i] last held chunk ci - 2, which was drained (hence copied) before this iteration
-            self.channels(prep, out=dev[i][:cnt], user_begin=b, user_count=cnt, variant=variant, tx_codebook=tx_codebook)
+            self.channels(prep, out=dev[i][:cnt], user_begin=user_begin + b, user_count=cnt, variant=variant, tx_codebook=tx_codebook)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 stage[i][:cnt * per_user].copy_(dev[i][:cnt].reshape(-1), non_blocking=True)

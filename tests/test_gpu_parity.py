@@ -747,6 +747,12 @@ def test_numpy_output_pipeline_equals_resident_tensor(mode):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
         got2 = ds2.compute_beam_channels(F, p) if mode == "beams" else ds2.compute_channels(p)   # staging buffers reused
         assert np.array_equal(got2.view(np.uint32), want.view(np.uint32))
+        if mode != "beams":                                   # iter_channels: the same pipeline inside every yielded chunk
+            seen = 0
+            for b, chunk in ds2.iter_channels(p, chunk_users=450):
+                assert np.array_equal(chunk.view(np.uint32), want[b:b + len(chunk)].view(np.uint32))
+                seen += len(chunk)
+            assert seen == len(want)
     finally:
         eng.HOST_CHUNK_BYTES = old
         dm.config.reset()
