@@ -27,6 +27,8 @@ struct WsView {
     int32_t* n_keep;  // [n]     compacted paths per user
     int64_t  n;
     int32_t  P;
+    float    neg_one; // -1.0f as a kernel-argument SGPR the compiler cannot fold: the multiplier of the f16 split's
+                      // residual fma, so that it is selected as v_fma_mix_f32 (k2_mfma_frag.h, split2_f16)
 };
 
 __host__ __device__ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -48,6 +50,7 @@ __host__ inline size_t ws_carve(void* base, int64_t n, int32_t P, WsView* v) {
         v->dop_v = (float*)(b + o_dv); v->dop_a = (float*)(b + o_da);
         v->n_keep = (int32_t*)(b + o_keep);
         v->n = n; v->P = P;
+        v->neg_one = -1.0f;
     }
     return off;
 }

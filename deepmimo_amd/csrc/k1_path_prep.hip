@@ -42,6 +42,8 @@ struct PrepArgs {
     int doppler;
     int rx_filter;
     int need_angles;                       // angles wanted as numbers (side outputs, FoV, dipole), not just directions
+    int sort_paths;                        // frequency domain: kept paths ordered by falling amplitude (the sum does not care;
+                                           // stage 2 drops product terms of a weak last K-step, k2_channel_fd_mfma.hip)
     double fc;
 };
 
@@ -295,8 +297,18 @@ __global__ __launch_bounds__(256, LEAN ? 4 : 2) void k1_path_prep(PrepArgs a) {
             ry = a.ue_spacing * (sqrt(1.0 - zc_r * zc_r) * (rho_r > 0.0 ? im_r / rho_r : 0.0)); rz = a.ue_spacing * zc_r;
         }
         const unsigned long long kb = group_mask<LPU>(__ballot(keep), grp);
+        int rank = 0;
+        const bool sorted = a.sort_paths && L <= LPU;          // kernel-uniform; the whole user is in this one pass
+        if (sorted) {
+            // rank among the kept paths by |c|^2, ties by path index: 0 = strongest.  Lanes that keep nothing carry -1.
+            const float key = keep ? c_re * c_re + c_im * c_im : -1.0f;
+            for (int jj = 0; jj < L; ++jj) {
+                const float kj = __shfl(key, jj, LPU);
+                rank += (kj > key || (kj == key && jj < lane)) ? 1 : 0;
+            }
+        }
         if (keep) {
-            const int slot = keep_base + __popcll(kb & ((1ull << lane) - 1ull));
+            const int slot = sorted ? rank : keep_base + __popcll(kb & ((1ull << lane) - 1ull));
             a.ws.c_re[wrow + slot] = c_re; a.ws.c_im[wrow + slot] = c_im; a.ws.dn[wrow + slot] = dn;
             a.ws.tx_y[wrow + slot] = ty; a.ws.tx_z[wrow + slot] = tz;
             a.ws.rx_y[wrow + slot] = ry; a.ws.rx_z[wrow + slot] = rz;
@@ -345,6 +357,7 @@ int launch_path_prep(const dmx_rays& rays, const dmx_params& prm, const WsView& 
     a.P = ws.P; a.freq_domain = prm.freq_domain; a.n_sc = prm.n_subcarriers;
     a.ts32 = (float)(1.0 / prm.bandwidth);
     a.doppler = prm.enable_doppler; a.fc = prm.carrier_freq; a.rx_filter = prm.rx_filter && prm.freq_domain;
+    a.sort_paths = prm.freq_domain ? 1 : 0;                // the time-domain slots keep the path order (channel.py:285-287)
     a.need_angles = prm.fov_enabled || prm.bs_pattern != DMX_PATTERN_ISOTROPIC || prm.ue_pattern != DMX_PATTERN_ISOTROPIC ||
                     side.aod_el_rot || side.aod_az_rot || side.aoa_el_rot || side.aoa_az_rot;
     if (rays.n_ue == 0) return DMX_OK;

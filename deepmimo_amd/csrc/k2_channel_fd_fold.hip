@@ -52,24 +52,28 @@ struct FoldArgs {
     int nsuper;        // ceil(nblk / sch): work items per user
     int nb_last;       // blocks of the last inner chunk
     int tab_rows;      // rows of the row tables (multiple of 32)
+    int adaptive;      // 1 = a weak last K-step may take one product term
     int k_tail;        // K - 16*(nblk-1): valid subcarriers of the last block (1..16)
 };
 
 typedef float fv2 __attribute__((ext_vector_type(2)));
 
-// x = hi + lo in f16.  The residual x - hi is ONE mixed-precision fma per value: v_fma_mix_f32 reads the f16 half of
-// the packed register directly (op_sel_hi marks the operand as f16, op_sel picks the half) - the compiler's own form
-// is v_cvt_f32_f16 + v_sub_f32, two instructions per value in a kernel whose time is its VALU count.
-__device__ __forceinline__ void fold_split2(float x0, float x1, fh2& hi, fh2& lo) {
+// x = hi + lo in f16.  The residual x - hi is ONE mixed-precision fma per value (v_fma_mix_f32 reads the f16 half of the
+// packed register in place) - selected by the compiler from fma(f16 -> f32, m1, x) with m1 = WsView::neg_one; see k2_mfma_frag.h for why
+// this is no longer inline asm.
+__device__ __forceinline__ void fold_split2(float x0, float x1, fh2& hi, fh2& lo, float m1) {
     const fhp2 h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-    const unsigned hb = __builtin_bit_cast(unsigned, h);
-    float r0, r1;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hb), "v"(x0));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "v"(x1));
+    const fh2 hh = __builtin_bit_cast(fh2, h);
+    const float r0 = __builtin_fmaf((float)hh[0], m1, x0);
+    const float r1 = __builtin_fmaf((float)hh[1], m1, x1);
     const fhp2 l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
-    hi = __builtin_bit_cast(fh2, h);
+    hi = hh;
     lo = __builtin_bit_cast(fh2, l);
 }
+
+// float -> its bits, by VALUE: __builtin_bit_cast applied directly to a vector-element lvalue (`bit_cast(unsigned, v[i])`)
+// reads element 0 whatever i is with this compiler; through a by-value parameter it is the element asked for
+__device__ __forceinline__ unsigned fold_bits(float x) { return __builtin_bit_cast(unsigned, x); }
 
 // (a + jb)(c + jd) as two packed instructions: [ac, ad] then fma([-b, b], [d, c], .)
 __device__ __forceinline__ fv2 fold_cmul(float a, float b, float c, float d) {
@@ -93,6 +97,69 @@ template <int WS>
 __device__ __forceinline__ void fold_sync() {
     if constexpr (WS == 4) __syncthreads();
     else wave_lds_sync();
+}
+
+// One 32-row tile (a,p) x 32 columns: NS K-steps of A' = Ac[p][l] E1[a][l] (complex products, then the f16 hi / lo split)
+// against the item's E2' fragments, and the un-scaling of the accumulator.  NS and LW (weak last K-step: A'hi B'hi only,
+// no A'lo built) are template parameters and each K-step's MFMAs are fenced with sched_barrier on purpose.  Two round-2
+// builds of this loop - K-steps guarded at run time with the adaptive branch inside, and a templated one whose MFMAs the
+// scheduler interleaved with the next split - were NOT bit-reproducible: two identical launches differed in one
+// 16-subcarrier block (accumulator registers 8..15, the ones an MFMA writes last) for ~0.5 % of the users, while every
+// parity test on a few hundred users stayed green.  What exactly raced was not pinned down: tools/mfma_war_probe.hip,
+// mfma_dep_probe.hip and mfma_raw_probe.hip show that on this chip MFMA sources are latched at issue (overwriting them in
+// the next instruction is harmless), that dependent MFMAs are interlocked at any distance, and that a vector read of the
+// LAST accumulator register needs 12 wait states behind the MFMA where the compiler's table says 11 - none of which this
+// loop violates on paper.  The present shape is bit-reproducible over 150k users x 3 launches
+// (tests/test_gpu_parity.py::test_launches_are_bit_reproducible), and that test is what guards it.
+template <int NS, bool LW>
+__device__ __forceinline__ ff16 fold_tile(const unsigned char* arow, const unsigned char* erow, const fh8 (&Bhi)[4],
+                                          const fh8 (&Blo)[4], float m1, float oscale) {
+    ff16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const float4 x0 = *reinterpret_cast<const float4*>(arow + s * 64);
+        const float4 x1 = *reinterpret_cast<const float4*>(arow + s * 64 + 16);
+        const float4 y0 = *reinterpret_cast<const float4*>(erow + s * 64);
+        const float4 y1 = *reinterpret_cast<const float4*>(erow + s * 64 + 16);
+        const fv2 z0 = fold_cmul(x0.x, x0.y, y0.x, y0.y), z1 = fold_cmul(x0.z, x0.w, y0.z, y0.w);
+        const fv2 z2 = fold_cmul(x1.x, x1.y, y1.x, y1.y), z3 = fold_cmul(x1.z, x1.w, y1.z, y1.w);
+        fh8 Ah;
+        if (LW && s == NS - 1) {
+            const fh2 p0 = __builtin_bit_cast(fh2, __builtin_amdgcn_cvt_pkrtz(z0[0], z0[1]));
+            const fh2 p1 = __builtin_bit_cast(fh2, __builtin_amdgcn_cvt_pkrtz(z1[0], z1[1]));
+            const fh2 p2 = __builtin_bit_cast(fh2, __builtin_amdgcn_cvt_pkrtz(z2[0], z2[1]));
+            const fh2 p3 = __builtin_bit_cast(fh2, __builtin_amdgcn_cvt_pkrtz(z3[0], z3[1]));
+            Ah[0] = p0[0]; Ah[1] = p0[1]; Ah[2] = p1[0]; Ah[3] = p1[1]; Ah[4] = p2[0]; Ah[5] = p2[1]; Ah[6] = p3[0]; Ah[7] = p3[1];
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bhi[s], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            fh8 Al;
+            fh2 ph, pl;
+            fold_split2(z0[0], z0[1], ph, pl, m1);
+            Ah[0] = ph[0]; Ah[1] = ph[1]; Al[0] = pl[0]; Al[1] = pl[1];
+            fold_split2(z1[0], z1[1], ph, pl, m1);
+            Ah[2] = ph[0]; Ah[3] = ph[1]; Al[2] = pl[0]; Al[3] = pl[1];
+            fold_split2(z2[0], z2[1], ph, pl, m1);
+            Ah[4] = ph[0]; Ah[5] = ph[1]; Al[4] = pl[0]; Al[5] = pl[1];
+            fold_split2(z3[0], z3[1], ph, pl, m1);
+            Ah[6] = ph[0]; Ah[7] = ph[1]; Al[6] = pl[0]; Al[7] = pl[1];
+            // The three MFMAs stay together behind the code that builds their A operands, nothing scheduled between them
+            // (the shape this loop had while the split was inline asm, which the scheduler does not move code across).
+            // Builds in which the scheduler threaded the next values' split through the MFMAs returned one corrupted
+            // 16-subcarrier block for ~0.5 % of the users, differently on every launch; see the note above fold_tile.
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bhi[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Blo[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bhi[s], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] *= oscale;
+    return acc;
 }
 
 // WS = waves sharing a work item: 1 - every wave owns its items and tables (few antenna pairs: the tables are small, no
@@ -172,6 +239,13 @@ __global__ __launch_bounds__(256, WS == 1 ? 5 : 4) void k2_fd_fold(WsView ws, Fo
         const double txy = ok ? ws.tx_y[rb] : 0.0, txz = ok ? ws.tx_z[rb] : 0.0;
         float m = fmaxf(fabsf(cr), fabsf(ci));
         for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        // adaptive precision as in k2_channel_fd_mfma.hip (stage_item): a last K-step whose paths are all <= 2^-11 of the
+        // strongest one in amplitude is multiplied out in one f16 term (here: A'hi only is built for it)
+        const int l0w = ((n_act - 1) >> 3) << 3;
+        const float a2 = fmaf(cr, cr, ci * ci);
+        float m2 = a2, mw2 = lp >= l0w ? a2 : 0.f;
+        for (int off = 16; off > 0; off >>= 1) { m2 = fmaxf(m2, __shfl_xor(m2, off)); mw2 = fmaxf(mw2, __shfl_xor(mw2, off)); }
+        const bool last_weak = a.adaptive && l0w >= 8 && mw2 * 4194304.0f <= m2;
         int e;
         (void)frexpf(m, &e);                                               // m = f * 2^e, f in [0.5, 1)
         const float gs = ldexpf(1.0f, 10 - e);                             // max |c| component -> [512, 1024)
@@ -196,6 +270,9 @@ __global__ __launch_bounds__(256, WS == 1 ? 5 : 4) void k2_fd_fold(WsView ws, Fo
         // kk = 16s + 8h + j, i.e. path 8s + 4h + (j>>1), component j&1.  Column c = 0 holds (Re G, -Im G) = (cos, sin)
         // of the phase, column c = 1 holds (Im G, Re G) = the same pair a quarter revolution later.
         const int nsteps = (n_act + 7) >> 3;
+        // wave-uniform by construction, and made scalar for the compiler: a divergent switch around MFMAs (which ignore the
+        // EXEC mask) is not something to leave to the structurizer
+        const int tile_kind = __builtin_amdgcn_readfirstlane(2 * nsteps + (last_weak ? 1 : 0));
         fh8 Bhi[4], Blo[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -209,7 +286,7 @@ __global__ __launch_bounds__(256, WS == 1 ? 5 : 4) void k2_fd_fold(WsView ws, Fo
                     float sn, cs;
                     sincos_rev(fmaf(qq.y, kbf, p1 - rintf(p1)), sn, cs);
                     fh2 ph, pl;
-                    fold_split2(cs * FOLD_B_SCALE, sn * FOLD_B_SCALE, ph, pl);
+                    fold_split2(cs * FOLD_B_SCALE, sn * FOLD_B_SCALE, ph, pl, ws.neg_one);
                     Bhi[s][2 * jj] = ph[0]; Bhi[s][2 * jj + 1] = ph[1];
                     Blo[s][2 * jj] = pl[0]; Blo[s][2 * jj + 1] = pl[1];
                 }
@@ -245,54 +322,34 @@ __global__ __launch_bounds__(256, WS == 1 ? 5 : 4) void k2_fd_fold(WsView ws, Fo
             const uint32_t src = rowsrc[(rt << 5) + lp];
             const unsigned char* arow = Ac + (src >> 16) + hh * 32;
             const unsigned char* erow = E1 + (src & 0xFFFFu) + hh * 32;
-            ff16 acc;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if (s < nsteps) {
-                    const float4 x0 = *reinterpret_cast<const float4*>(arow + s * 64);
-                    const float4 x1 = *reinterpret_cast<const float4*>(arow + s * 64 + 16);
-                    const float4 y0 = *reinterpret_cast<const float4*>(erow + s * 64);
-                    const float4 y1 = *reinterpret_cast<const float4*>(erow + s * 64 + 16);
-                    fh8 Ah, Al;
-                    fh2 ph, pl;
-                    fv2 z = fold_cmul(x0.x, x0.y, y0.x, y0.y);
-                    fold_split2(z[0], z[1], ph, pl);
-                    Ah[0] = ph[0]; Ah[1] = ph[1]; Al[0] = pl[0]; Al[1] = pl[1];
-                    z = fold_cmul(x0.z, x0.w, y0.z, y0.w);
-                    fold_split2(z[0], z[1], ph, pl);
-                    Ah[2] = ph[0]; Ah[3] = ph[1]; Al[2] = pl[0]; Al[3] = pl[1];
-                    z = fold_cmul(x1.x, x1.y, y1.x, y1.y);
-                    fold_split2(z[0], z[1], ph, pl);
-                    Ah[4] = ph[0]; Ah[5] = ph[1]; Al[4] = pl[0]; Al[5] = pl[1];
-                    z = fold_cmul(x1.z, x1.w, y1.z, y1.w);
-                    fold_split2(z[0], z[1], ph, pl);
-                    Ah[6] = ph[0]; Ah[7] = ph[1]; Al[6] = pl[0]; Al[7] = pl[1];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bhi[s], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Blo[s], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bhi[s], acc, 0, 0, 0);
-                }
+            ff16 sv;                                                       // the tile, un-scaled: register i is row
+            switch (tile_kind) {                                           // (i&3) + 8*(i>>2) + 4*(lane>>5), column lane&31
+                case 2: sv = fold_tile<1, false>(arow, erow, Bhi, Blo, ws.neg_one, oscale); break;
+                case 4: sv = fold_tile<2, false>(arow, erow, Bhi, Blo, ws.neg_one, oscale); break;
+                case 5: sv = fold_tile<2, true>(arow, erow, Bhi, Blo, ws.neg_one, oscale); break;
+                case 6: sv = fold_tile<3, false>(arow, erow, Bhi, Blo, ws.neg_one, oscale); break;
+                case 7: sv = fold_tile<3, true>(arow, erow, Bhi, Blo, ws.neg_one, oscale); break;
+                case 8: sv = fold_tile<4, false>(arow, erow, Bhi, Blo, ws.neg_one, oscale); break;
+                default: sv = fold_tile<4, true>(arow, erow, Bhi, Blo, ws.neg_one, oscale); break;
             }
-            // accumulator register i is row (i&3) + 8*(i>>2) + 4*(lane>>5) of the tile, column lane&31
             const uint4* ro4 = reinterpret_cast<const uint4*>(rowoff + (rt << 5) + 4 * hh);
             if (masked) {                                                  // wave-uniform: partial last block in this item
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const uint4 ro = ro4[2 * g];
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * g + 0] * oscale), orsrc, lane_col + (ro.x & lmask_last), 0, NT ? 2 : 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * g + 1] * oscale), orsrc, lane_col + (ro.y & lmask_last), 0, NT ? 2 : 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * g + 2] * oscale), orsrc, lane_col + (ro.z & lmask_last), 0, NT ? 2 : 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * g + 3] * oscale), orsrc, lane_col + (ro.w & lmask_last), 0, NT ? 2 : 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 0]), orsrc, lane_col + (ro.x & lmask_last), 0, NT ? 2 : 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 1]), orsrc, lane_col + (ro.y & lmask_last), 0, NT ? 2 : 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 2]), orsrc, lane_col + (ro.z & lmask_last), 0, NT ? 2 : 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 3]), orsrc, lane_col + (ro.w & lmask_last), 0, NT ? 2 : 0);
                 }
             } else {                                                       // rows past the item carry 0xC0000000: out of range as they are
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const uint4 ro = ro4[2 * g];
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * g + 0] * oscale), orsrc, lane_col + ro.x, 0, NT ? 2 : 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * g + 1] * oscale), orsrc, lane_col + ro.y, 0, NT ? 2 : 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * g + 2] * oscale), orsrc, lane_col + ro.z, 0, NT ? 2 : 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[4 * g + 3] * oscale), orsrc, lane_col + ro.w, 0, NT ? 2 : 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 0]), orsrc, lane_col + ro.x, 0, NT ? 2 : 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 1]), orsrc, lane_col + ro.y, 0, NT ? 2 : 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 2]), orsrc, lane_col + ro.z, 0, NT ? 2 : 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 3]), orsrc, lane_col + ro.w, 0, NT ? 2 : 0);
                 }
             }
         }
@@ -385,6 +442,7 @@ int launch_channels_fd_fold(const dmx_params& prm, const WsView& ws, int64_t use
     a.nb_last = a.nblk - a.ch * (a.nchunk - 1);
     a.tab_rows = (a.M * a.ch + 31) / 32 * 32;
     a.k_tail = a.K - 16 * (a.nblk - 1);
+    a.adaptive = getenv("DMX_NO_ADAPTIVE") == nullptr;              // env = measurement hook: always three terms
     if ((size_t)a.M * (size_t)a.K * 8 >= (size_t)1 << 30) { set_error("%d x %d outputs per user are too many for the folded kernel", a.M, a.K); return DMX_ERR_SHAPE; }
     const size_t smem = fold_static_bytes(a.tab_rows, a.M) + sets * fold_wave_bytes(a.M, a.ch);
     if (smem > 160 * 1024) { set_error("folded kernel tables of %zu bytes exceed LDS", smem); return DMX_ERR_SHAPE; }

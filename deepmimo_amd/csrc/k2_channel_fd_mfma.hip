@@ -49,6 +49,7 @@ struct MfmaArgs {
     // rx_filter variant: per-path subcarrier gains precomputed by k3_lpf_* instead of generated here
     const float2* gtab;      // [user_count, P, K] or nullptr
     const uint2* gpack;      // the same table in packed f16 hi/lo form (load_b_step_packed) or nullptr
+    int adaptive;            // 1 = a weak last K-step may take one product term (stage_item)
 };
 
 // One 32-row tile of one strip: 2*NS ds_read_b128 of A' issued together, 3*NS MFMAs, 16 stores.  NS = K-steps that
@@ -58,7 +59,7 @@ struct MfmaArgs {
 // buffer descriptor over this workgroup's row block: the per-lane part of the address is one 32-bit voffset per
 // strip, the row of each store is a scalar soffset, and rows past the block end fall outside num_records and are
 // dropped by the hardware range check.
-template <bool NT, int NS>
+template <bool NT, int NS, bool LW>
 __device__ __forceinline__ void mfma_tile(int pt, const unsigned char* Ahi, const unsigned char* Alo, int col, int hh,
                                           const h8 (&Bhi)[4], const h8 (&Blo)[4], const BLane& bl,
                                           __amdgpu_buffer_rsrc_t orsrc, unsigned row_bytes, float oscale) {
@@ -76,6 +77,7 @@ __device__ __forceinline__ void mfma_tile(int pt, const unsigned char* Ahi, cons
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], Bhi[s], acc, 0, 0, 0);
+        if (LW && s == NS - 1) continue;        // weak last K-step: one product term (stage_item, "last_weak")
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], Blo[s], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], Bhi[s], acc, 0, 0, 0);
     }
@@ -94,7 +96,7 @@ __device__ __forceinline__ void mfma_tile(int pt, const unsigned char* Ahi, cons
 // nothing against eight tiles per strip, +11-15 % on row blocks of one or two tiles (16 / 64 rows x 512 subcarriers:
 // 3.6 -> 4.0 and 5.5 -> 6.4 ms per 100k users).  The grouped and pipelined kernels (MODE 1, 2) are therefore only launched for >= 128-row blocks.
 template <bool NT>
-__device__ __forceinline__ void mfma_tile_rt(int pt, const unsigned char* Ahi, const unsigned char* Alo, int col, int hh, int n_act,
+__device__ __forceinline__ void mfma_tile_rt(int pt, const unsigned char* Ahi, const unsigned char* Alo, int col, int hh, int n_act, int n_full,
                                              const h8 (&Bhi)[4], const h8 (&Blo)[4], const BLane& bl,
                                              __amdgpu_buffer_rsrc_t orsrc, unsigned row_bytes, float oscale) {
     f16v acc;
@@ -107,8 +109,10 @@ __device__ __forceinline__ void mfma_tile_rt(int pt, const unsigned char* Ahi, c
             const h8 ah = *reinterpret_cast<const h8*>(Ahi + abase + s * 32);
             const h8 al = *reinterpret_cast<const h8*>(Alo + abase + s * 32);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bhi[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Blo[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bhi[s], acc, 0, 0, 0);
+            if (s < n_full) {                   // K-steps from n_full on are weak: one product term
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Blo[s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bhi[s], acc, 0, 0, 0);
+            }
         }
     }
     if (bl.kok) {
@@ -136,7 +140,7 @@ __device__ __forceinline__ void store_rows(const f16v& acc, float oscale, const 
 }
 
 // chain of tile `pt` into a fresh accumulator while `prev` (tile pt - 1) is stored, a few rows after every K-step
-template <bool NT, int NS, bool STORE_PREV>
+template <bool NT, int NS, bool STORE_PREV, bool LW>
 __device__ __forceinline__ f16v chain_tile(int pt, const f16v& prev, const unsigned char* Ahi, const unsigned char* Alo, int col, int hh,
                                            const h8 (&Bhi)[4], const h8 (&Blo)[4], const BLane& bl,
                                            __amdgpu_buffer_rsrc_t orsrc, unsigned row_bytes, float oscale) {
@@ -150,8 +154,10 @@ __device__ __forceinline__ f16v chain_tile(int pt, const f16v& prev, const unsig
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bhi[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Blo[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bhi[s], acc, 0, 0, 0);
+        if (!(LW && s == NS - 1)) {            // weak last K-step: one product term
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Blo[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bhi[s], acc, 0, 0, 0);
+        }
         if (s + 1 < NS) {                      // next K-step's fragments: the read latency passes behind the stores below
             ah = *reinterpret_cast<const h8*>(Ahi + abase + (s + 1) * 32);
             al = *reinterpret_cast<const h8*>(Alo + abase + (s + 1) * 32);
@@ -179,24 +185,24 @@ __device__ __forceinline__ f16v chain_tile(int pt, const f16v& prev, const unsig
     return acc;
 }
 
-template <bool NT, int NS, bool PIPE>
+template <bool NT, int NS, bool PIPE, bool LW>
 __device__ __forceinline__ void strip_tiles(int ntiles, const unsigned char* Ahi, const unsigned char* Alo, int col, int hh,
                                             const h8 (&Bhi)[4], const h8 (&Blo)[4], const BLane& bl,
                                             __amdgpu_buffer_rsrc_t orsrc, unsigned row_bytes, float oscale) {
     if constexpr (!PIPE) {
         for (int pt = 0; pt < ntiles; ++pt)
-            mfma_tile<NT, NS>(pt, Ahi, Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale);
+            mfma_tile<NT, NS, LW>(pt, Ahi, Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale);
         return;
     }
     f16v a0 = {};
-    a0 = chain_tile<NT, NS, false>(0, a0, Ahi, Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale);
+    a0 = chain_tile<NT, NS, false, LW>(0, a0, Ahi, Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale);
     int pt = 1;
     for (; pt + 1 < ntiles; pt += 2) {                                   // a0 holds tile pt - 1
-        const f16v a1 = chain_tile<NT, NS, true>(pt, a0, Ahi, Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale);
-        a0 = chain_tile<NT, NS, true>(pt + 1, a1, Ahi, Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale);
+        const f16v a1 = chain_tile<NT, NS, true, LW>(pt, a0, Ahi, Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale);
+        a0 = chain_tile<NT, NS, true, LW>(pt + 1, a1, Ahi, Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale);
     }
     if (pt < ntiles) {
-        const f16v a1 = chain_tile<NT, NS, true>(pt, a0, Ahi, Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale);
+        const f16v a1 = chain_tile<NT, NS, true, LW>(pt, a0, Ahi, Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale);
         store_rows<NT, 0, 16>(a1, oscale, bl, orsrc, (unsigned)(pt << 5) * row_bytes, row_bytes);
     } else {
         store_rows<NT, 0, 16>(a0, oscale, bl, orsrc, (unsigned)((ntiles - 1) << 5) * row_bytes, row_bytes);
@@ -266,9 +272,22 @@ __device__ __forceinline__ void stage_item(const WsView& ws, const MfmaArgs& a, 
         float m = 0.f;
         if (lane < n_act) m = fmaxf(fabsf(c_re[lane]), fabsf(c_im[lane]));
         for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        // Adaptive precision: when every path of the LAST K-step (stage 1 orders the kept paths by falling amplitude) is
+        // at least 66 dB below the user's strongest one - |c| <= 2^-11 max |c| - that K-step's products are taken as
+        // A'hi B'hi alone: each then carries a relative error of at most 2^-9 (both factors truncated to f16) instead of
+        // 2^-21, i.e. at most 8 paths x 2^-20 = 7.6e-6 of the strongest path's amplitude in the worst case (1e-6 rms), next
+        // to the 2e-6 the 3-term products leave and the 5e-5 tolerance (test_adaptive_precision_weak_tail_worst_case).
+        // Saves 2 of the 12 MFMAs per tile whenever the last K-step is weak (25 kept paths: it holds the weakest one).
+        const int l0w = ((n_act - 1) >> 3) << 3;
+        float a2 = 0.f;
+        if (lane < n_act) a2 = fmaf(c_re[lane], c_re[lane], c_im[lane] * c_im[lane]);
+        float m2 = a2, mw2 = lane >= l0w ? a2 : 0.f;
+        for (int off = 32; off > 0; off >>= 1) { m2 = fmaxf(m2, __shfl_xor(m2, off)); mw2 = fmaxf(mw2, __shfl_xor(mw2, off)); }
+        const bool last_weak = a.adaptive && l0w >= 8 && mw2 * 4194304.0f <= m2;    // |c|^2 ratio 2^-22
         int e;
         (void)frexpf(m, &e);                                             // m = f * 2^e, f in [0.5, 1)
         const float gs = ldexpf(1.0f, 10 - e);
+        if (lane == 0) L.misc[3] = last_weak ? 1.f : 0.f;
         if (lane < LPAD) {
             const bool ok = lane < n_act;
             const double q = ok ? (double)dnp[lane] * a.inv_n : 0.0;
@@ -306,7 +325,7 @@ __device__ __forceinline__ void stage_item(const WsView& ws, const MfmaArgs& a, 
                 float s, c;
                 sincos_rev(frac_rev(yr * rx_y[l] + zr * rx_z[l]), s, c);
                 const float2 f = frow[l];
-                split2_f16((c * f.x - s * f.y) * ascale, (c * f.y + s * f.x) * ascale, vh, vl);
+                split2_f16((c * f.x - s * f.y) * ascale, (c * f.y + s * f.x) * ascale, vh, vl, ws.neg_one);
             }
             rhi[l] = vh;
             rlo[l] = vl;
@@ -318,7 +337,7 @@ __device__ __forceinline__ void stage_item(const WsView& ws, const MfmaArgs& a, 
                 const double ph = yr * rx_y[l] + zr * rx_z[l] + yt * tx_y[l] + zt * tx_z[l];
                 float s, c;
                 sincos_rev(frac_rev(ph), s, c);
-                split2_f16(c * A_SCALE, s * A_SCALE, vh, vl);
+                split2_f16(c * A_SCALE, s * A_SCALE, vh, vl, ws.neg_one);
             }
             rhi[l] = vh;
             rlo[l] = vl;
@@ -347,6 +366,7 @@ __device__ __forceinline__ void consume_item(const WsView& ws, const MfmaArgs& a
     }
     const float oscale = L.misc[0];
     const float gscale = L.misc[2];
+    const bool last_weak = L.misc[3] != 0.f;                             // workgroup-uniform
     const float2* grow = GSRC == 1 ? a.gtab + (size_t)ip.ul * ws.P * a.K : nullptr;
     const uint2* prow = GSRC == 2 ? a.gpack + (size_t)ip.ul * ws.P * a.K : nullptr;
 
@@ -362,7 +382,7 @@ __device__ __forceinline__ void consume_item(const WsView& ws, const MfmaArgs& a
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
             if constexpr (GSRC == 2) load_b_step_packed(st, bl, hh, n_act, prow, a.K, Bhi[st], Blo[st]);
-            else gen_b_step(st, bl, hh, n_act, L.qtab, L.crtab, L.citab, grow, a.K, gscale, Bhi[st], Blo[st]);
+            else gen_b_step(ws.neg_one, st, bl, hh, n_act, L.qtab, L.crtab, L.citab, grow, a.K, gscale, Bhi[st], Blo[st]);
         }
         if constexpr (GSRC == 2) {
             // The table reads are cold HBM misses in front of a dependent MFMA chain (with every user aliased to one
@@ -381,15 +401,19 @@ __device__ __forceinline__ void consume_item(const WsView& ws, const MfmaArgs& a
         }
         if constexpr (MODE != 0) {
             constexpr bool PIPE = MODE == 2;
-            switch ((n_act + 7) >> 3) {                                   // workgroup-uniform
-                case 1: strip_tiles<NT, 1, PIPE>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
-                case 2: strip_tiles<NT, 2, PIPE>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
-                case 3: strip_tiles<NT, 3, PIPE>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
-                default: strip_tiles<NT, 4, PIPE>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
+            switch (((n_act + 7) >> 3) + (last_weak ? 4 : 0)) {           // workgroup-uniform
+                case 1: strip_tiles<NT, 1, PIPE, false>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
+                case 2: strip_tiles<NT, 2, PIPE, false>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
+                case 3: strip_tiles<NT, 3, PIPE, false>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
+                case 4: strip_tiles<NT, 4, PIPE, false>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
+                case 6: strip_tiles<NT, 2, PIPE, true>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
+                case 7: strip_tiles<NT, 3, PIPE, true>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
+                default: strip_tiles<NT, 4, PIPE, true>(ntiles, L.Ahi, L.Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale); break;
             }
         } else {
+            const int n_full = ((n_act + 7) >> 3) - (last_weak ? 1 : 0);
             for (int pt = 0; pt < ntiles; ++pt)
-                mfma_tile_rt<NT>(pt, L.Ahi, L.Alo, col, hh, n_act, Bhi, Blo, bl, orsrc, row_bytes, oscale);
+                mfma_tile_rt<NT>(pt, L.Ahi, L.Alo, col, hh, n_act, n_full, Bhi, Blo, bl, orsrc, row_bytes, oscale);
         }
     }
 }
@@ -501,7 +525,7 @@ __global__ __launch_bounds__(256) void k2b_beam_project_mfma(WsView ws, BeamArgs
         h2 vh = {(_Float16)0.f, (_Float16)0.f}, vl = vh;
         if (b < B && t < a.m_tx) {
             const float2 w = a.F[(size_t)b * a.m_tx + t];
-            split2_f16(w.x * sF, w.y * sF, vh, vl);
+            split2_f16(w.x * sF, w.y * sF, vh, vl, ws.neg_one);
         }
         reinterpret_cast<h2*>(Fhi + (size_t)b * fstride)[t] = vh;
         reinterpret_cast<h2*>(Flo + (size_t)b * fstride)[t] = vl;
@@ -553,7 +577,7 @@ __global__ __launch_bounds__(256) void k2b_beam_project_mfma(WsView ws, BeamArgs
                     const float e0 = c ? gi[jj] : gr[jj];
                     const float e1 = c ? gr[jj] : -gi[jj];
                     h2 ph, pl2;
-                    split2_f16(e0, e1, ph, pl2);
+                    split2_f16(e0, e1, ph, pl2, ws.neg_one);
                     Bh[2 * jj] = ph[0]; Bh[2 * jj + 1] = ph[1];
                     Bl[2 * jj] = pl2[0]; Bl[2 * jj + 1] = pl2[1];
                 }
@@ -715,6 +739,7 @@ static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user
                            const float2* gtab, hipStream_t stream, const uint2* gpack) {
     MfmaArgs a;
     a.n_beams = n_beams; a.ftab = ftab; a.fexp = fexp; a.gtab = gtab; a.gpack = gpack;
+    a.adaptive = !n_beams && !gtab && !gpack && !getenv("DMX_NO_ADAPTIVE");   // env = measurement hook: always three terms
     a.user_begin = user_begin;
     a.m_rx = prm.ue_shape[0] * prm.ue_shape[1];
     a.m_tx = prm.bs_shape[0] * prm.bs_shape[1];

@@ -21,14 +21,18 @@ static constexpr float A_SCALE = 64.0f;      // 2^6
 // op_sel picks the half); the compiler's own form is v_cvt_f32_f16 + v_sub_f32.  Same-box A/B at the headline shape
 // (tools/ab_two_libs.sh): 15.80 vs 16.21 ms.
 typedef __fp16 hp2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split2_f16(float x0, float x1, h2& hi, h2& lo) {
+// m1 = WsView::neg_one, i.e. -1.0f arriving as a kernel argument: fma(f16 -> f32, m1, x) is selected as ONE
+// v_fma_mix_f32 reading the f16 half in place, while with a literal -1.0f (or a constant the compiler can see) the
+// expression is canonicalised to x - h and becomes v_cvt_f32_f16 + v_sub_f32.  (Until late in round 2 this was inline
+// asm; compiler-selected instructions are visible to the hazard recognizer, asm operands are not - no inline asm next
+// to MFMAs.)
+__device__ __forceinline__ void split2_f16(float x0, float x1, h2& hi, h2& lo, float m1) {
     const hp2 h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-    const unsigned hb = __builtin_bit_cast(unsigned, h);
-    float r0, r1;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hb), "v"(x0));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "v"(x1));
+    const h2 hh = __builtin_bit_cast(h2, h);
+    const float r0 = __builtin_fmaf((float)hh[0], m1, x0);
+    const float r1 = __builtin_fmaf((float)hh[1], m1, x1);
     const hp2 l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
-    hi = __builtin_bit_cast(h2, h);
+    hi = hh;
     lo = __builtin_bit_cast(h2, l);
 }
 
@@ -54,7 +58,7 @@ __device__ __forceinline__ BLane b_lane(int strip, int col, int hh, size_t twoK,
 }
 
 // one K-step (8 paths) of the strip's B' fragments
-__device__ __forceinline__ void gen_b_step(int s, const BLane& bl, int hh, int n_act, const float2* qtab, const float* crtab,
+__device__ __forceinline__ void gen_b_step(float m1, int s, const BLane& bl, int hh, int n_act, const float2* qtab, const float* crtab,
                                            const float* citab, const float2* __restrict__ grow, int K, float gs,
                                            h8& Bhi, h8& Blo) {
     Bhi = h8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -96,7 +100,7 @@ __device__ __forceinline__ void gen_b_step(int s, const BLane& bl, int hh, int n
         const float e0 = c ? gi[jj] : gr[jj];                           // row 2l   : Re G (re col) / Im G (im col)
         const float e1 = c ? gr[jj] : -gi[jj];                          // row 2l+1 : -Im G        / Re G
         h2 ph, pl2;
-        split2_f16(e0, e1, ph, pl2);
+        split2_f16(e0, e1, ph, pl2, m1);
         Bhi[2 * jj] = ph[0]; Bhi[2 * jj + 1] = ph[1];
         Blo[2 * jj] = pl2[0]; Blo[2 * jj + 1] = pl2[1];
     }

@@ -42,6 +42,7 @@ struct BeamPowArgs {
     const int32_t* fexp;     // [user_count]
     float* out;              // [user_count, n_beams] mean amplitude
     int32_t* best;           // [user_count] argmax_b (first maximum), -1 without paths; may be nullptr
+    int adaptive;            // 1 = a weak last K-step may take one product term
 };
 
 __host__ __device__ inline size_t beam_pow_lds_bytes(int M, int NW) {
@@ -83,6 +84,13 @@ __global__ __launch_bounds__(NW * 64, 4) void k2c_beam_power(WsView ws, BeamPowA
             float m = 0.f;
             if (lane < n_act) m = fmaxf(fabsf(ws.c_re[rb + lane]), fabsf(ws.c_im[rb + lane]));
             for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+            // adaptive precision as in k2_channel_fd_mfma.hip (stage_item): weak last K-step -> one product term
+            const int l0w = ((n_act - 1) >> 3) << 3;
+            float a2 = 0.f;
+            if (lane < n_act) a2 = fmaf(ws.c_re[rb + lane], ws.c_re[rb + lane], ws.c_im[rb + lane] * ws.c_im[rb + lane]);
+            float m2 = a2, mw2 = lane >= l0w ? a2 : 0.f;
+            for (int off = 32; off > 0; off >>= 1) { m2 = fmaxf(m2, __shfl_xor(m2, off)); mw2 = fmaxf(mw2, __shfl_xor(mw2, off)); }
+            if (lane == 0) misc[3] = (a.adaptive && l0w >= 8 && mw2 * 4194304.0f <= m2) ? 1.f : 0.f;
             int e;
             (void)frexpf(m, &e);
             const float gs = ldexpf(1.0f, 10 - e);
@@ -99,6 +107,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k2c_beam_power(WsView ws, BeamPowA
         }
         __syncthreads();
         const float ascale = misc[1];
+        const int nfull = ((n_act + 7) >> 3) - (misc[3] != 0.f ? 1 : 0);     // K-steps with all three product terms
 
         for (int blk = 0; blk < nblk; ++blk) {
             const int row0 = blk * MAX_ROWS;
@@ -129,7 +138,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k2c_beam_power(WsView ws, BeamPowA
                                 float sn, cs;
                                 sincos_rev(frac_rev(yr * ws.rx_y[rb + pl] + zr * ws.rx_z[rb + pl]), sn, cs);
                                 const float2 f = frow[pl];
-                                split2_f16((cs * f.x - sn * f.y) * ascale, (cs * f.y + sn * f.x) * ascale, vh, vl);
+                                split2_f16((cs * f.x - sn * f.y) * ascale, (cs * f.y + sn * f.x) * ascale, vh, vl, ws.neg_one);
                             }
                             Ah[s][2 * jj] = vh[0]; Ah[s][2 * jj + 1] = vh[1];
                             Al[s][2 * jj] = vl[0]; Al[s][2 * jj + 1] = vl[1];
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k2c_beam_power(WsView ws, BeamPowA
                         sincos_rev(fmaf(q.y, kf, p1 - rintf(p1)), sn, cs);
                         const float cr = crtab[pl], ci = citab[pl];
                         h2 vh, vl;
-                        split2_f16(cr * cs + ci * sn, ci * cs - cr * sn, vh, vl);       // (Re G, Im G), G = c e^{-jx}
+                        split2_f16(cr * cs + ci * sn, ci * cs - cr * sn, vh, vl, ws.neg_one);       // (Re G, Im G), G = c e^{-jx}
                         const unsigned hb = __builtin_bit_cast(unsigned, vh), lb = __builtin_bit_cast(unsigned, vl);
                         const h2 reh = __builtin_bit_cast(h2, hb ^ 0x80000000u), rel = __builtin_bit_cast(h2, lb ^ 0x80000000u);
                         const h2 imh = __builtin_bit_cast(h2, __builtin_amdgcn_alignbit(hb, hb, 16));
@@ -196,6 +205,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k2c_beam_power(WsView ws, BeamPowA
                                 const h8 ih = slot[(4 * s + 2) * 64 + lane], il = slot[(4 * s + 3) * 64 + lane];
                                 are = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[s], rh, are, 0, 0, 0);
                                 aim = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[s], ih, aim, 0, 0, 0);
+                                if (s >= nfull) continue;
                                 are = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[s], rl, are, 0, 0, 0);
                                 aim = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[s], il, aim, 0, 0, 0);
                                 are = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[s], rh, are, 0, 0, 0);
@@ -272,6 +282,7 @@ int launch_beam_power(const dmx_params& prm, const WsView& ws, int64_t user_begi
     a.fexp = t.fexp;
     a.out = out_amp;
     a.best = out_best;
+    a.adaptive = getenv("DMX_NO_ADAPTIVE") == nullptr;              // env = measurement hook: always three terms
     int nw = 8;
     if (const char* env = getenv("DMX_BEAM_WAVES")) nw = atoi(env) == 4 ? 4 : 8;      // measurement hook
     const size_t smem = beam_pow_lds_bytes(a.M, nw);

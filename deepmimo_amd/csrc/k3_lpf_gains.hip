@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256, K3_WAVES_PER_SIMD) void k3_lpf_fft_wave(WsView
                         const float2 g = src[binreg[j]];
                         if (a.pack) {
                             h2 hi, lo;
-                            split2_f16(g.x * gsl, g.y * gsl, hi, lo);
+                            split2_f16(g.x * gsl, g.y * gsl, hi, lo, ws.neg_one);
                             prow[k] = make_uint2(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo));
                         } else {
                             grow[k] = g;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256, K3_WAVES_PER_SIMD) void k3_lpf_fft_wave(WsView
                     const float2 g = src[fpad(a.sc[k] & (N - 1))];                // N is a power of two: floor-mod
                     if (a.pack) {
                         h2 hi, lo;
-                        split2_f16(g.x * gsl, g.y * gsl, hi, lo);
+                        split2_f16(g.x * gsl, g.y * gsl, hi, lo, ws.neg_one);
                         prow[k] = make_uint2(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo));
                     } else {
                         grow[k] = g;
