@@ -230,6 +230,7 @@ def main():
     ap.add_argument("--users", type=int, default=0, help="override users per GPU")
     ap.add_argument("--cpu-users", type=int, default=-1, help="CPU baseline sample size (0 = skip)")
     ap.add_argument("--random-valid", action="store_true", help="valid paths per user uniform in 0..L")
+    ap.add_argument("--skip-three-terms", action="store_true", help="no extra launches with the adaptive-precision rule off (profiling runs: one kind of launch only)")
     ap.add_argument("--cpu-workers", type=int, default=-1, help="processes of the all-cores CPU figure (default min(16, cores))")
     ap.add_argument("--gather", action="store_true", help="N > 1: also time the side-product all_gather and a bounded channel-slice gather to rank 0")
     ap.add_argument("--gather-users", type=int, default=2048, help="users per rank in the gathered channel slice")
@@ -348,7 +349,7 @@ def main():
     # the same stage 2 with the adaptive-precision rule off (every K-step in three product terms), outside the timed region:
     # reported beside the number above so that the rule's share of it is on the line
     k2_ms_3t = None
-    if args.steps and not (w.get("td") or w.get("lpf")):
+    if args.steps and not (w.get("td") or w.get("lpf")) and not args.skip_three_terms:
         os.environ["DMX_NO_ADAPTIVE"] = "1"                        # read by the launchers at every call
         try:
             step()
