@@ -326,6 +326,23 @@ def main():
         if ev1 is not None:
             ev1.record(torch.cuda.current_stream(dev))
 
+    # the same stage 2 with the adaptive-precision rule off (every K-step in three product terms), BEFORE the warm-up and
+    # the timed region and outside both: reported beside the timed number so that the rule's share of it is on the line
+    # 
+    k2_ms_3t = None
+    if args.steps and not (w.get("td") or w.get("lpf")) and not args.skip_three_terms:
+        os.environ["DMX_NO_ADAPTIVE"] = "1"                        # read by the launchers at every call
+        try:
+            for _ in range(8):                                     # the chip ramps its clocks over the first launches: a fair
+                step()                                             # comparison needs this leg as warm as the timed one below
+            ev3 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(5, args.steps))]
+            for a_, b_ in ev3:
+                step(a_, b_)
+            torch.cuda.synchronize(dev)
+            k2_ms_3t = float(np.mean([a_.elapsed_time(b_) for a_, b_ in ev3]))
+        finally:
+            os.environ.pop("DMX_NO_ADAPTIVE", None)
+
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
@@ -345,23 +362,6 @@ def main():
         t = torch.tensor([elapsed, k2_ms], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, k2_ms = float(t[0]), float(t[1])
-
-    # the same stage 2 with the adaptive-precision rule off (every K-step in three product terms), outside the timed region:
-    # reported beside the number above so that the rule's share of it is on the line
-    k2_ms_3t = None
-    if args.steps and not (w.get("td") or w.get("lpf")) and not args.skip_three_terms:
-        os.environ["DMX_NO_ADAPTIVE"] = "1"                        # read by the launchers at every call
-        try:
-            step()
-            ev3 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(3, args.steps))]
-            for a_, b_ in ev3:
-                step(a_, b_)
-            torch.cuda.synchronize(dev)
-            k2_ms_3t = float(np.mean([a_.elapsed_time(b_) for a_, b_ in ev3]))
-        finally:
-            os.environ.pop("DMX_NO_ADAPTIVE", None)
-        step()                                                     # leave the adaptive result in `out` for the check below
-        torch.cuda.synchronize(dev)
 
     # a cheap end-to-end sanity check of what was just written (not timed)
     chk = out[:: max(1, n_ue // 64)]
