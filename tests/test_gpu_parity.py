@@ -759,8 +759,9 @@ def test_numpy_output_pipeline_equals_resident_tensor(mode):
         dm.config.reset()
 
 
-@pytest.mark.parametrize("kind", ["fold_16x256", "fold_shared_64x256", "mfma_256x512", "mfma_rt_64x256", "mfma_rt_16x512",
-                                  "beam_power", "beam_power_1rx", "rx_filter"])
+@pytest.mark.parametrize("kind", ["fold_16x256", "fold_shared_64x256", "mfma_256x512", "mfma_256x512_v3", "mfma_256x512_v4",
+                                  "mfma_256x512_v5", "mfma_256x512_v8", "mfma_256x512_v10", "mfma_256x512_v11", "mfma_rt_64x256",
+                                  "mfma_rt_16x512", "beam_power", "beam_power_1rx", "rx_filter"])
 def test_launches_are_bit_reproducible(kind):
     """The same launch three times gives the same bits, on enough users that a one-in-a-thousand hazard shows.  A
     round-2 build of the folded kernel (K-steps guarded at run time, the accumulator first read in another basic block
@@ -771,10 +772,13 @@ def test_launches_are_bit_reproducible(kind):
     from deepmimo_amd.engine import ChannelEngine
     from oracle import oracle_np as onp
     cfg = {"fold_16x256": (150_000, [4, 4], [1, 1], 256), "fold_shared_64x256": (60_000, [8, 8], [1, 1], 256),
-           "mfma_256x512": (6_000, [8, 8], [2, 2], 512), "beam_power": (6_000, [8, 8], [2, 2], 512),
+           "mfma_256x512": (30_000, [8, 8], [2, 2], 512), "beam_power": (30_000, [8, 8], [2, 2], 512),
+           "mfma_256x512_v3": (6_000, [8, 8], [2, 2], 512), "mfma_256x512_v4": (6_000, [8, 8], [2, 2], 512),
+           "mfma_256x512_v5": (6_000, [8, 8], [2, 2], 512), "mfma_256x512_v8": (6_000, [8, 8], [2, 2], 512),
+           "mfma_256x512_v10": (6_000, [8, 8], [2, 2], 512), "mfma_256x512_v11": (6_000, [8, 8], [2, 2], 512),
            "mfma_rt_64x256": (20_000, [8, 8], [1, 1], 256), "mfma_rt_16x512": (40_000, [4, 4], [1, 1], 512),
            "beam_power_1rx": (20_000, [8, 8], [1, 1], 256),
-           "rx_filter": (4_000, [8, 8], [2, 2], 512)}[kind]
+           "rx_filter": (10_000, [8, 8], [2, 2], 512)}[kind]
     n, bs, ue, N = cfg
     rays = onp.synth_rays(n, 25, seed=77)
     p = dm.ChannelGenParameters()
@@ -792,6 +796,8 @@ def test_launches_are_bit_reproducible(kind):
             assert torch.equal(r, runs[0])
         return
     variant = 2 if kind.startswith("mfma") else 0                  # mfma_rt_*: the run-time-guarded tile body of small row blocks
+    if "_v" in kind:
+        variant = int(kind.rsplit("_v", 1)[1])                     # the other forms of the matrix-core kernel the ABI exposes
     first = eng.channels(prep, variant=variant).clone()
     for _ in range(2):
         again = eng.channels(prep, variant=variant)
