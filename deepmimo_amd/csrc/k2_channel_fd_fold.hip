@@ -101,16 +101,20 @@ __device__ __forceinline__ void fold_sync() {
 
 // One 32-row tile (a,p) x 32 columns: NS K-steps of A' = Ac[p][l] E1[a][l] (complex products, then the f16 hi / lo split)
 // against the item's E2' fragments, and the un-scaling of the accumulator.  NS and LW (weak last K-step: A'hi B'hi only,
-// no A'lo built) are template parameters and each K-step's MFMAs are fenced with sched_barrier on purpose.  Two round-2
-// builds of this loop - K-steps guarded at run time with the adaptive branch inside, and a templated one whose MFMAs the
-// scheduler interleaved with the next split - were NOT bit-reproducible: two identical launches differed in one
-// 16-subcarrier block (accumulator registers 8..15, the ones an MFMA writes last) for ~0.5 % of the users, while every
-// parity test on a few hundred users stayed green.  What exactly raced was not pinned down: tools/mfma_war_probe.hip,
-// mfma_dep_probe.hip and mfma_raw_probe.hip show that on this chip MFMA sources are latched at issue (overwriting them in
-// the next instruction is harmless), that dependent MFMAs are interlocked at any distance, and that a vector read of the
-// LAST accumulator register needs 12 wait states behind the MFMA where the compiler's table says 11 - none of which this
-// loop violates on paper.  The present shape is bit-reproducible over 150k users x 3 launches
-// (tests/test_gpu_parity.py::test_launches_are_bit_reproducible), and that test is what guards it.
+// no A'lo built) are template parameters, each K-step's MFMAs are fenced with sched_barrier, and the choice of (NS, LW) is
+// made OUTSIDE the tile loop (fold_tiles below) on purpose.  Three round-2 builds of this loop were not bit-reproducible:
+// K-steps guarded at run time with the adaptive branch inside, a templated body whose MFMAs the scheduler interleaved with
+// the next split (two identical launches differed in one 16-subcarrier block - accumulator registers 8..15, the ones an
+// MFMA writes last - for ~0.5 % of the users), and a per-tile `switch` over the templated bodies, which the compiler turned
+// into a cascade of blocks shared between the cases (the same corruption for 1 user-launch in 10 million, only with the
+// adaptive rule on).  Every parity test on a few hundred users stayed green through all three.  What exactly races was
+// not pinned down: tools/mfma_war_probe.hip, mfma_dep_probe.hip and mfma_raw_probe.hip show that on this chip MFMA sources
+// are latched at issue, that dependent MFMAs are interlocked at any distance, and that a vector read of the LAST
+// accumulator register needs 12 wait states behind the MFMA where the compiler's table says 11 - none of which those loops
+// violated on paper.  The present shape - one loop nest per (NS, LW), every tile straight-line from its first LDS read to
+// its last store, as in k2_channel_fd_mfma.hip - shows 0 differing users in 240 million user-launches
+// (tools/repro_stress.py); tests/test_gpu_parity.py::test_launches_are_bit_reproducible and the stress test in
+// tests/test_gpu_fullsize.py guard it.
 template <int NS, bool LW>
 __device__ __forceinline__ ff16 fold_tile(const unsigned char* arow, const unsigned char* erow, const fh8 (&Bhi)[4],
                                           const fh8 (&Blo)[4], float m1, float oscale) {
@@ -160,6 +164,41 @@ __device__ __forceinline__ ff16 fold_tile(const unsigned char* arow, const unsig
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] *= oscale;
     return acc;
+}
+
+// The row tiles of one inner chunk for a fixed (NS, LW): tile body (fold_tile) and its 16 stores.
+template <bool NT, int WS, int NS, bool LW>
+__device__ __forceinline__ void fold_tiles(int sub, int ntiles, const uint32_t* rowsrc, const uint32_t* rowoff, int lp, int hh,
+                                           const unsigned char* Ac, const unsigned char* E1, const fh8 (&Bhi)[4], const fh8 (&Blo)[4],
+                                           float m1, float oscale, bool masked, __amdgpu_buffer_rsrc_t orsrc, uint32_t lane_col,
+                                           uint32_t lmask_last) {
+    for (int rt = sub; rt < ntiles; rt += WS) {
+        const uint32_t src = rowsrc[(rt << 5) + lp];
+        const unsigned char* arow = Ac + (src >> 16) + hh * 32;
+        const unsigned char* erow = E1 + (src & 0xFFFFu) + hh * 32;
+        // the tile, un-scaled: register i is row (i&3) + 8*(i>>2) + 4*(lane>>5), column lane&31
+        const ff16 sv = fold_tile<NS, LW>(arow, erow, Bhi, Blo, m1, oscale);
+        const uint4* ro4 = reinterpret_cast<const uint4*>(rowoff + (rt << 5) + 4 * hh);
+        if (masked) {                                                  // wave-uniform: partial last block in this item
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint4 ro = ro4[2 * g];
+                __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 0]), orsrc, lane_col + (ro.x & lmask_last), 0, NT ? 2 : 0);
+                __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 1]), orsrc, lane_col + (ro.y & lmask_last), 0, NT ? 2 : 0);
+                __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 2]), orsrc, lane_col + (ro.z & lmask_last), 0, NT ? 2 : 0);
+                __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 3]), orsrc, lane_col + (ro.w & lmask_last), 0, NT ? 2 : 0);
+            }
+        } else {                                                       // rows past the item carry 0xC0000000: out of range as they are
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint4 ro = ro4[2 * g];
+                __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 0]), orsrc, lane_col + ro.x, 0, NT ? 2 : 0);
+                __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 1]), orsrc, lane_col + ro.y, 0, NT ? 2 : 0);
+                __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 2]), orsrc, lane_col + ro.z, 0, NT ? 2 : 0);
+                __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 3]), orsrc, lane_col + ro.w, 0, NT ? 2 : 0);
+            }
+        }
+    }
 }
 
 // WS = waves sharing a work item: 1 - every wave owns its items and tables (few antenna pairs: the tables are small, no
@@ -318,40 +357,16 @@ __global__ __launch_bounds__(256, WS == 1 ? 5 : 4) void k2_fd_fold(WsView ws, Fo
         const int ntiles = (rows + 31) >> 5;
         const __amdgpu_buffer_rsrc_t orsrc =
             __builtin_amdgcn_make_buffer_rsrc(o, 0, (int)((unsigned)(user_floats - (size_t)a0 * 32) * 4u), 0x00020000);
-        for (int rt = sub; rt < ntiles; rt += WS) {
-            const uint32_t src = rowsrc[(rt << 5) + lp];
-            const unsigned char* arow = Ac + (src >> 16) + hh * 32;
-            const unsigned char* erow = E1 + (src & 0xFFFFu) + hh * 32;
-            ff16 sv;                                                       // the tile, un-scaled: register i is row
-            switch (tile_kind) {                                           // (i&3) + 8*(i>>2) + 4*(lane>>5), column lane&31
-                case 2: sv = fold_tile<1, false>(arow, erow, Bhi, Blo, ws.neg_one, oscale); break;
-                case 4: sv = fold_tile<2, false>(arow, erow, Bhi, Blo, ws.neg_one, oscale); break;
-                case 5: sv = fold_tile<2, true>(arow, erow, Bhi, Blo, ws.neg_one, oscale); break;
-                case 6: sv = fold_tile<3, false>(arow, erow, Bhi, Blo, ws.neg_one, oscale); break;
-                case 7: sv = fold_tile<3, true>(arow, erow, Bhi, Blo, ws.neg_one, oscale); break;
-                case 8: sv = fold_tile<4, false>(arow, erow, Bhi, Blo, ws.neg_one, oscale); break;
-                default: sv = fold_tile<4, true>(arow, erow, Bhi, Blo, ws.neg_one, oscale); break;
-            }
-            const uint4* ro4 = reinterpret_cast<const uint4*>(rowoff + (rt << 5) + 4 * hh);
-            if (masked) {                                                  // wave-uniform: partial last block in this item
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const uint4 ro = ro4[2 * g];
-                    __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 0]), orsrc, lane_col + (ro.x & lmask_last), 0, NT ? 2 : 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 1]), orsrc, lane_col + (ro.y & lmask_last), 0, NT ? 2 : 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 2]), orsrc, lane_col + (ro.z & lmask_last), 0, NT ? 2 : 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 3]), orsrc, lane_col + (ro.w & lmask_last), 0, NT ? 2 : 0);
-                }
-            } else {                                                       // rows past the item carry 0xC0000000: out of range as they are
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const uint4 ro = ro4[2 * g];
-                    __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 0]), orsrc, lane_col + ro.x, 0, NT ? 2 : 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 1]), orsrc, lane_col + ro.y, 0, NT ? 2 : 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 2]), orsrc, lane_col + ro.z, 0, NT ? 2 : 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 3]), orsrc, lane_col + ro.w, 0, NT ? 2 : 0);
-                }
-            }
+        // one loop nest per (K-steps, weak last step): the choice is made out here, so that inside a loop every tile is
+        // the same straight-line code from its first LDS read to its last store
+        switch (tile_kind) {
+            case 2: fold_tiles<NT, WS, 1, false>(sub, ntiles, rowsrc, rowoff, lp, hh, Ac, E1, Bhi, Blo, ws.neg_one, oscale, masked, orsrc, lane_col, lmask_last); break;
+            case 4: fold_tiles<NT, WS, 2, false>(sub, ntiles, rowsrc, rowoff, lp, hh, Ac, E1, Bhi, Blo, ws.neg_one, oscale, masked, orsrc, lane_col, lmask_last); break;
+            case 5: fold_tiles<NT, WS, 2, true>(sub, ntiles, rowsrc, rowoff, lp, hh, Ac, E1, Bhi, Blo, ws.neg_one, oscale, masked, orsrc, lane_col, lmask_last); break;
+            case 6: fold_tiles<NT, WS, 3, false>(sub, ntiles, rowsrc, rowoff, lp, hh, Ac, E1, Bhi, Blo, ws.neg_one, oscale, masked, orsrc, lane_col, lmask_last); break;
+            case 7: fold_tiles<NT, WS, 3, true>(sub, ntiles, rowsrc, rowoff, lp, hh, Ac, E1, Bhi, Blo, ws.neg_one, oscale, masked, orsrc, lane_col, lmask_last); break;
+            case 8: fold_tiles<NT, WS, 4, false>(sub, ntiles, rowsrc, rowoff, lp, hh, Ac, E1, Bhi, Blo, ws.neg_one, oscale, masked, orsrc, lane_col, lmask_last); break;
+            default: fold_tiles<NT, WS, 4, true>(sub, ntiles, rowsrc, rowoff, lp, hh, Ac, E1, Bhi, Blo, ws.neg_one, oscale, masked, orsrc, lane_col, lmask_last); break;
         }
         }                                                                  // inner chunks
     }
