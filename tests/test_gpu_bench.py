@@ -34,3 +34,9 @@ def test_bench_workload_line(workload, users, kernel, bound):
     assert d["value"] == pytest.approx(users / (d["ms_per_step"] * 1e-3), rel=1e-6)
     if workload == "c5_massive":
         assert "Doppler" in d["config"]["workload"]
+    # the adaptive-precision rule's share is on the line for the kernels that have it, and only for them
+    has_rule = kernel in ("k2_fd_mfma", "k2_fd_fold", "k2c_beam_power")
+    assert ("kernel_ms_all_three_terms" in rf) == has_rule
+    if has_rule:
+        assert rf["kernel_ms_all_three_terms"] > 0 and rf["frac_all_three_terms"] == pytest.approx(rf["frac"] * rf["kernel_ms"] / rf["kernel_ms_all_three_terms"])
+        assert "adaptive rule" in d["config"]["arithmetic"]
