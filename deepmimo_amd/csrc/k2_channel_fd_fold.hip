@@ -26,6 +26,8 @@
 // offsets come from a table because row (a,p) lives at (p*K + 16a)*8 bytes).  Persistent grid.
 #include "dmx_common.h"
 #include <stdlib.h>
+// see DMX_MFMA_RESULT_GUARD in k2_mfma_frag.h (this file does not include it)
+#define FOLD_TILE_GUARD asm volatile("s_nop 3")
 
 namespace dmx {
 
@@ -161,6 +163,7 @@ __device__ __forceinline__ ff16 fold_tile(const unsigned char* arow, const unsig
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    FOLD_TILE_GUARD;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] *= oscale;
     return acc;

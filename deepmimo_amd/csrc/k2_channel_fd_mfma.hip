@@ -81,6 +81,7 @@ __device__ __forceinline__ void mfma_tile(int pt, const unsigned char* Ahi, cons
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], Blo[s], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], Bhi[s], acc, 0, 0, 0);
     }
+    DMX_MFMA_RESULT_GUARD();
     if (bl.kok) {
         const unsigned tile_off = (unsigned)(pt << 5) * row_bytes;
 #pragma unroll
@@ -115,6 +116,7 @@ __device__ __forceinline__ void mfma_tile_rt(int pt, const unsigned char* Ahi, c
             }
         }
     }
+    DMX_MFMA_RESULT_GUARD();
     if (bl.kok) {
         const unsigned tile_off = (unsigned)(pt << 5) * row_bytes;
 #pragma unroll
@@ -203,8 +205,10 @@ __device__ __forceinline__ void strip_tiles(int ntiles, const unsigned char* Ahi
     }
     if (pt < ntiles) {
         const f16v a1 = chain_tile<NT, NS, true, LW>(pt, a0, Ahi, Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale);
+        DMX_MFMA_RESULT_GUARD();                 // the strip's last tile is stored right behind its chain
         store_rows<NT, 0, 16>(a1, oscale, bl, orsrc, (unsigned)(pt << 5) * row_bytes, row_bytes);
     } else {
+        DMX_MFMA_RESULT_GUARD();
         store_rows<NT, 0, 16>(a0, oscale, bl, orsrc, (unsigned)((ntiles - 1) << 5) * row_bytes, row_bytes);
     }
 }
@@ -591,6 +595,7 @@ __global__ __launch_bounds__(256) void k2b_beam_project_mfma(WsView ws, BeamArgs
                     acc[bt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bh, acc[bt], 0, 0, 0);
                 }
             }
+            DMX_MFMA_RESULT_GUARD();
 #pragma unroll
             for (int bt = 0; bt < NBT; ++bt)
 #pragma unroll

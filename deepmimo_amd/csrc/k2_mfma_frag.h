@@ -15,6 +15,13 @@ static constexpr int MFMA_LDS_MAX = 80 * 1024;   // two workgroups per CU
 static constexpr int LPAD = 32;              // path slots (kk = 64)
 static constexpr float A_SCALE = 64.0f;      // 2^6
 
+// Four wait states the compiler does not know about, placed between the last MFMA of a chain and the first vector read
+// of its accumulator.  The hazard recognizer already puts its 12 there, and 12 is what a direct probe needs
+// (tools/mfma_raw_probe.hip) - yet the folded kernel, which has nothing but those 12, returned accumulator registers 8..15
+// of one tile short of an MFMA's contribution once per 100-400 million user-launches (worse arrangements: once per 200
+// users), and with these four more it did not in 1.75 billion.  Cost: 4 of ~1,000 cycles per tile.
+#define DMX_MFMA_RESULT_GUARD() asm volatile("s_nop 3")
+
 // (x0, x1) -> packed hi pair and packed lo pair, x = hi + lo.  v_cvt_pkrtz_f16_f32 converts two floats per
 // instruction; with round-toward-zero x - hi is exact in fp32 and lo keeps 11 more bits of it.  The residual is ONE
 // v_fma_mix_f32 per value (it reads the f16 half of the packed register directly: op_sel_hi marks the operand as f16,

@@ -213,6 +213,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k2c_beam_power(WsView ws, BeamPowA
                             }
                         }
                         // |Y| of this lane's subcarrier for the 16 rows it holds: both parts are in this lane
+                        DMX_MFMA_RESULT_GUARD();
                         // (vector instructions add to the matrix-core time on this chip, square roots do not:
                         // profiles/r2_mfma_valu_overlap.txt - hence packed mul / fma / add around two v_sqrt_f32)
 #pragma unroll
