@@ -120,9 +120,15 @@ __device__ __forceinline__ void fold_sync() {
 template <int NS, bool LW>
 __device__ __forceinline__ ff16 fold_tile(const unsigned char* arow, const unsigned char* erow, const fh8 (&Bhi)[4],
                                           const fh8 (&Blo)[4], float m1, float oscale) {
-    ff16 acc;
+    // TWO accumulators, even and odd K-steps: an MFMA then never accumulates onto the result of the K-step just before it,
+    // only onto the one two steps back, long finished.  With one accumulator the first MFMA of K-step s + 1 was issued about
+    // one K-step's A' construction (~120 cycles) behind the three MFMAs of K-step s (96 cycles of matrix pipe) - right around
+    // the moment their last pass wrote accumulator registers 8..15 - and on some boxes of the pool, once in 10^7...10^9
+    // users, those registers went into the next MFMA without the last contribution (every build that
+    // moved dependent MFMAs towards that distance failed more often, the ones that moved them away less).
+    ff16 acc[2];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const float4 x0 = *reinterpret_cast<const float4*>(arow + s * 64);
@@ -139,7 +145,7 @@ __device__ __forceinline__ ff16 fold_tile(const unsigned char* arow, const unsig
             const fh2 p3 = __builtin_bit_cast(fh2, __builtin_amdgcn_cvt_pkrtz(z3[0], z3[1]));
             Ah[0] = p0[0]; Ah[1] = p0[1]; Ah[2] = p1[0]; Ah[3] = p1[1]; Ah[4] = p2[0]; Ah[5] = p2[1]; Ah[6] = p3[0]; Ah[7] = p3[1];
             __builtin_amdgcn_sched_barrier(0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bhi[s], acc, 0, 0, 0);
+            acc[s & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bhi[s], acc[s & 1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         } else {
             fh8 Al;
@@ -152,21 +158,20 @@ __device__ __forceinline__ ff16 fold_tile(const unsigned char* arow, const unsig
             Ah[4] = ph[0]; Ah[5] = ph[1]; Al[4] = pl[0]; Al[5] = pl[1];
             fold_split2(z3[0], z3[1], ph, pl, m1);
             Ah[6] = ph[0]; Ah[7] = ph[1]; Al[6] = pl[0]; Al[7] = pl[1];
-            // The three MFMAs stay together behind the code that builds their A operands, nothing scheduled between them
-            // (the shape this loop had while the split was inline asm, which the scheduler does not move code across).
-            // Builds in which the scheduler threaded the next values' split through the MFMAs returned one corrupted
-            // 16-subcarrier block for ~0.5 % of the users, differently on every launch; see the note above fold_tile.
+            // the three MFMAs of a K-step stay together, back to back (dependent MFMAs issued back to back are the path
+            // every GEMM kernel exercises), nothing scheduled between or right behind them
             __builtin_amdgcn_sched_barrier(0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bhi[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Blo[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bhi[s], acc, 0, 0, 0);
+            acc[s & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bhi[s], acc[s & 1], 0, 0, 0);
+            acc[s & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Blo[s], acc[s & 1], 0, 0, 0);
+            acc[s & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bhi[s], acc[s & 1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     FOLD_TILE_GUARD;
+    ff16 out;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] *= oscale;
-    return acc;
+    for (int i = 0; i < 16; ++i) out[i] = (NS > 1 ? acc[0][i] + acc[1][i] : acc[0][i]) * oscale;
+    return out;
 }
 
 // The row tiles of one inner chunk for a fixed (NS, LW): tile body (fold_tile) and its 16 stores.
@@ -208,7 +213,7 @@ __device__ __forceinline__ void fold_tiles(int sub, int ntiles, const uint32_t* 
 // workgroup barrier anywhere); 4 - the workgroup works on one item with ONE set of tables and splits its row tiles over
 // the waves (33 ... 128 pairs: per-wave tables would leave one workgroup per CU).
 template <bool NT, int WS>
-__global__ __launch_bounds__(256, WS == 1 ? 5 : 4) void k2_fd_fold(WsView ws, FoldArgs a, float* __restrict__ out, int64_t items) {
+__global__ __launch_bounds__(256, 4) void k2_fd_fold(WsView ws, FoldArgs a, float* __restrict__ out, int64_t items) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* rowoff0 = reinterpret_cast<uint32_t*>(smem);                 // [tab_rows] byte offset of row (a,p), full chunk
     uint32_t* rowoff1 = rowoff0 + a.tab_rows;                              // [tab_rows] same for the last chunk
