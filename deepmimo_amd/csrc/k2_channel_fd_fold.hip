@@ -103,20 +103,23 @@ __device__ __forceinline__ void fold_sync() {
 
 // One 32-row tile (a,p) x 32 columns: NS K-steps of A' = Ac[p][l] E1[a][l] (complex products, then the f16 hi / lo split)
 // against the item's E2' fragments, and the un-scaling of the accumulator.  NS and LW (weak last K-step: A'hi B'hi only,
-// no A'lo built) are template parameters, each K-step's MFMAs are fenced with sched_barrier, and the choice of (NS, LW) is
-// made OUTSIDE the tile loop (fold_tiles below) on purpose.  Three round-2 builds of this loop were not bit-reproducible:
-// K-steps guarded at run time with the adaptive branch inside, a templated body whose MFMAs the scheduler interleaved with
-// the next split (two identical launches differed in one 16-subcarrier block - accumulator registers 8..15, the ones an
-// MFMA writes last - for ~0.5 % of the users), and a per-tile `switch` over the templated bodies, which the compiler turned
-// into a cascade of blocks shared between the cases (the same corruption for 1 user-launch in 10 million, only with the
-// adaptive rule on).  Every parity test on a few hundred users stayed green through all three.  What exactly races was
-// not pinned down: tools/mfma_war_probe.hip, mfma_dep_probe.hip and mfma_raw_probe.hip show that on this chip MFMA sources
-// are latched at issue, that dependent MFMAs are interlocked at any distance, and that a vector read of the LAST
-// accumulator register needs 12 wait states behind the MFMA where the compiler's table says 11 - none of which those loops
-// violated on paper.  The present shape - one loop nest per (NS, LW), every tile straight-line from its first LDS read to
-// its last store, as in k2_channel_fd_mfma.hip - shows 0 differing users in 240 million user-launches
-// (tools/repro_stress.py); tests/test_gpu_parity.py::test_launches_are_bit_reproducible and the stress test in
-// tests/test_gpu_fullsize.py guard it.
+// no A'lo built) are template parameters, each K-step's MFMAs are fenced with sched_barrier, the choice of (NS, LW) is made
+// OUTSIDE the tile loop (fold_tiles below), and even / odd K-steps accumulate into two different accumulators - all on
+// purpose.  Round 2 went through four builds of this loop that were not bit-reproducible: two identical launches differed
+// in accumulator registers 8..15 of one tile (the ones an MFMA writes in its last passes; 16 subcarriers x the tile's
+// second 16 rows), by 5e-4 ... 1e-1 of the user's peak - for 1 user in 200 (K-steps guarded at run time with the adaptive
+// branch inside; or the scheduler threading the next A' split between a K-step's MFMAs), for 1 user-launch in 10^7 on
+// every box (a per-tile switch that the compiler merged into shared blocks), and for 1 in 10^7...10^9 on SOME boxes of the
+// pool only (one accumulator, everything else as now).  Every parity test on a few hundred users stayed green throughout.
+// What the failing builds share: an MFMA that accumulates onto the result of an MFMA issued roughly one MFMA-group
+// duration earlier (32 ... 120 cycles), i.e. whose SrcC is being written back right when it is picked up; builds that moved
+// dependent MFMAs towards that distance failed more often (four hidden wait states behind every K-step's group: 1,000 x
+// more), builds that moved them away less.  Direct probes on boxes of unknown susceptibility show nothing of it
+// (tools/mfma_*_probe.hip: sources latched at issue, dependent MFMAs correct at every tested distance, 12 wait states for
+// the last accumulator register).  With two accumulators an MFMA only ever accumulates back to back onto its own K-step or
+// onto a K-step two steps back: on a box where the one-accumulator build differed in 14 of 600 million user-launches this
+// one differed in 0 of 1.4 billion (tools/hot_box_hunt.sh).  tests/test_gpu_parity.py::test_launches_are_bit_reproducible
+// and the stress tests in tests/test_gpu_fullsize.py guard it; tools/repro_stress.py is the long form.
 template <int NS, bool LW>
 __device__ __forceinline__ ff16 fold_tile(const unsigned char* arow, const unsigned char* erow, const fh8 (&Bhi)[4],
                                           const fh8 (&Blo)[4], float m1, float oscale) {
