@@ -230,7 +230,7 @@ def main():
     ap.add_argument("--users", type=int, default=0, help="override users per GPU")
     ap.add_argument("--cpu-users", type=int, default=-1, help="CPU baseline sample size (0 = skip)")
     ap.add_argument("--random-valid", action="store_true", help="valid paths per user uniform in 0..L")
-    ap.add_argument("--skip-three-terms", action="store_true", help="no extra launches with the adaptive-precision rule off (profiling runs: one kind of launch only)")
+    ap.add_argument("--skip-adaptive", action="store_true", help="no extra launches with the opt-in adaptive-precision flag (profiling runs: one kind of launch only)")
     ap.add_argument("--cpu-workers", type=int, default=-1, help="processes of the all-cores CPU figure (default min(16, cores))")
     ap.add_argument("--gather", action="store_true", help="N > 1: also time the side-product all_gather and a bounded channel-slice gather to rank 0")
     ap.add_argument("--gather-users", type=int, default=2048, help="users per rank in the gathered channel slice")
@@ -285,7 +285,10 @@ def main():
 
     # one preparation allocates the workspace once; every step then re-issues BOTH stages on the same buffers
     # (two C-ABI calls, no allocation, no host-device copy, no sync)
-    prep0 = eng.prepare(rays, params, want_side=False, carrier_freq=CARRIER_HZ if dop else 0.0)
+    # what the timed step runs is what Dataset.compute_channels runs: stage 1 in its "light" form (LoS, path counts - and
+    # the FoV mask when a FoV is set - written every step) and stage 2 in the API's default arithmetic (three product
+    # terms for every path, dmx_params.flags = 0)
+    prep0 = eng.prepare(rays, params, want_side="light", carrier_freq=CARRIER_HZ if dop else 0.0)
     p0, wsp = prep0.params_struct, C.c_void_p(prep0.workspace.data_ptr())
     assert bool(p0.enable_doppler) == dop, "the Doppler term of this workload is not active"
     if n_beams:
@@ -303,45 +306,46 @@ def main():
         lws = torch.empty(lws_bytes + 256, dtype=torch.uint8, device=dev)
         lws_ptr = lws.data_ptr() + (-lws.data_ptr()) % 256
 
-    def step(ev0=None, ev1=None):
+    def step(ev0=None, ev1=None, prep=None):
+        prep = prep or prep0
+        p = prep.params_struct
+        wsp_ = C.c_void_p(prep.workspace.data_ptr())
         stream = eng._stream_ptr()
-        prep0.side["max_delay_key"].zero_()
-        nat.check(eng.lib.dmx_path_prep(C.byref(prep0.rays_struct), C.byref(p0), wsp, prep0.workspace_bytes,
-                                        C.byref(prep0.side_struct), stream), "dmx_path_prep")
+        prep.side["max_delay_key"].zero_()
+        nat.check(eng.lib.dmx_path_prep(C.byref(prep.rays_struct), C.byref(p), wsp_, prep.workspace_bytes,
+                                        C.byref(prep.side_struct), stream), "dmx_path_prep")
         if ev0 is not None:
             ev0.record(torch.cuda.current_stream(dev))
         if n_beams:
-            nat.check(eng.lib.dmx_beam_power(C.byref(p0), wsp, prep0.n_ue, prep0.n_paths_loaded, 0, prep0.n_ue,
+            nat.check(eng.lib.dmx_beam_power(C.byref(p), wsp_, prep.n_ue, prep.n_paths_loaded, 0, prep.n_ue,
                                              C.c_void_p(cb.data_ptr()), n_beams, C.c_void_p(bws_ptr), bws_bytes,
                                              C.c_void_p(out.data_ptr()), C.c_void_p(best.data_ptr()), stream), "dmx_beam_power")
         elif w.get("td"):
-            nat.check(eng.lib.dmx_channels_td(C.byref(p0), wsp, prep0.n_ue, prep0.n_paths_loaded, 0, prep0.n_ue,
+            nat.check(eng.lib.dmx_channels_td(C.byref(p), wsp_, prep.n_ue, prep.n_paths_loaded, 0, prep.n_ue,
                                               C.c_void_p(out.data_ptr()), stream), "dmx_channels_td")
         elif w.get("lpf"):
-            nat.check(eng.lib.dmx_channels_fd_lpf(C.byref(p0), wsp, prep0.n_ue, prep0.n_paths_loaded, 0, prep0.n_ue,
+            nat.check(eng.lib.dmx_channels_fd_lpf(C.byref(p), wsp_, prep.n_ue, prep.n_paths_loaded, 0, prep.n_ue,
                                                   C.c_void_p(lws_ptr), lws_bytes, C.c_void_p(out.data_ptr()), stream), "dmx_channels_fd_lpf")
         else:
-            nat.check(eng.lib.dmx_channels_fd(C.byref(p0), wsp, prep0.n_ue, prep0.n_paths_loaded, 0, prep0.n_ue,
+            nat.check(eng.lib.dmx_channels_fd(C.byref(p), wsp_, prep.n_ue, prep.n_paths_loaded, 0, prep.n_ue,
                                               C.c_void_p(out.data_ptr()), int(args.variant), stream), "dmx_channels_fd")
         if ev1 is not None:
             ev1.record(torch.cuda.current_stream(dev))
 
-    # the same stage 2 with the adaptive-precision rule off (every K-step in three product terms), BEFORE the warm-up and
-    # the timed region and outside both: reported beside the timed number so that the rule's share of it is on the line
-    # 
-    k2_ms_3t = None
-    if args.steps and not (w.get("td") or w.get("lpf")) and not args.skip_three_terms:
-        os.environ["DMX_NO_ADAPTIVE"] = "1"                        # read by the launchers at every call
-        try:
-            for _ in range(8):                                     # the chip ramps its clocks over the first launches: a fair
-                step()                                             # comparison needs this leg as warm as the timed one below
-            ev3 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(5, args.steps))]
-            for a_, b_ in ev3:
-                step(a_, b_)
-            torch.cuda.synchronize(dev)
-            k2_ms_3t = float(np.mean([a_.elapsed_time(b_) for a_, b_ in ev3]))
-        finally:
-            os.environ.pop("DMX_NO_ADAPTIVE", None)
+    # the same two calls with the opt-in DMX_FLAG_ADAPTIVE_TERMS (a user's weak last path group in one product term),
+    # BEFORE the warm-up and the timed region and outside both: reported beside the timed number.  The flag is a field of
+    # the parameter block of a second preparation - nothing in the process changes.
+    k2_ms_ad = None
+    if args.steps and not (w.get("td") or w.get("lpf")) and not args.skip_adaptive:
+        prep_ad = eng.prepare(rays, params, want_side="light", carrier_freq=CARRIER_HZ if dop else 0.0, adaptive_terms=True)
+        for _ in range(8):                                         # the chip ramps its clocks over the first launches: a fair
+            step(prep=prep_ad)                                     # comparison needs this leg as warm as the timed one below
+        ev3 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(5, args.steps))]
+        for a_, b_ in ev3:
+            step(a_, b_, prep=prep_ad)
+        torch.cuda.synchronize(dev)
+        k2_ms_ad = float(np.mean([a_.elapsed_time(b_) for a_, b_ in ev3]))
+        del prep_ad
 
     for _ in range(args.warmup):
         step()
@@ -401,9 +405,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": note,
                 "kernel": f"stage-2 contraction ({kernel})", "kernel_ms": k2_ms,
                 "algorithmic_bytes_per_launch": n_ue * bytes_per_user}
-    if k2_ms_3t is not None and split:
-        roof["kernel_ms_all_three_terms"] = k2_ms_3t
-        roof["frac_all_three_terms"] = roof["frac"] * k2_ms / k2_ms_3t
+    if k2_ms_ad is not None and split:
+        roof["kernel_ms_adaptive_terms"] = k2_ms_ad
+        roof["frac_adaptive_terms"] = roof["frac"] * k2_ms / k2_ms_ad
     res = {
         "metric": "user-channels/sec", "value": total_users / step_s,
         "unit": "user-channels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -420,12 +424,14 @@ def main():
                    "fd_kernel_variant": args.variant, "fd_kernel": kernel, "library_id": library_id(),
                    "arithmetic": "fp32 results; the matrix-core kernels (k2_fd_mfma, k2_fd_fold, k2c_beam_power) contract "
                                  "f16 hi/lo splits of fp32 operands in 3 terms (hi*hi + hi*lo + lo*hi, fp32 accumulate; "
-                                 "<= 2e-6 of each user's peak measured against the float64 oracle); adaptive rule: a user's "
-                                 "last 8-path K-step is taken in ONE term when all its paths are >= 66 dB below the user's "
-                                 "strongest (<= 7.6e-6 of the strongest path worst case; fires for ~95 % of the synthetic "
-                                 "users because their powers are uniform over 80 dB, rarely on ray-traced data) - "
-                                 "roofline.kernel_ms_all_three_terms is the same launch with the rule off; the other "
-                                 "stage-2 kernels in fp32; stage 1 in float64",
+                                 "<= 2e-6 of each user's peak measured against the float64 oracle) for EVERY path - the "
+                                 "API's default and what `value` / `roofline.frac` are measured on; "
+                                 "roofline.kernel_ms_adaptive_terms is the same launch with the opt-in "
+                                 "dmx_params.flags = DMX_FLAG_ADAPTIVE_TERMS (a user's last 8-path group in ONE term when all "
+                                 "its paths are >= 66 dB below the user's strongest: <= 7.6e-6 of the strongest path worst "
+                                 "case; fires for ~95 % of the synthetic users because their powers are uniform over 80 dB, "
+                                 "rarely on ray-traced data); the other stage-2 kernels in fp32; stage 1 in float64",
+                   "stage1_side_products": "light (los, num_paths written every step)",
                    "complex_macs_per_s": cmacs * world / step_s},
         "roofline": roof,
     }

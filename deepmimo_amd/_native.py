@@ -11,7 +11,8 @@ import os
 # DMX_LIB_PATH lets a measurement load another build of the same ABI (A/B of two libraries); default = in-tree
 LIB_PATH = os.environ.get("DMX_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
                                                           "libdeepmimo_amd.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
+FLAG_ADAPTIVE_TERMS = 1
 
 EXPORTED_SYMBOLS = ("dmx_version", "dmx_last_error", "dmx_workspace_bytes", "dmx_decode_max_delay",
                     "dmx_path_prep", "dmx_channels_fd", "dmx_channels_td", "dmx_channels_fd_lpf",
@@ -44,7 +45,8 @@ class DmxParams(C.Structure):
                 ("n_subcarriers", C.c_int32), ("n_selected", C.c_int32),
                 ("selected_subcarriers", C.c_void_p),
                 ("bandwidth", C.c_double), ("rx_filter", C.c_int32), ("enable_doppler", C.c_int32),
-                ("carrier_freq", C.c_double), ("sc_first", C.c_int32), ("sc_stride", C.c_int32)]
+                ("carrier_freq", C.c_double), ("sc_first", C.c_int32), ("sc_stride", C.c_int32),
+                ("flags", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 class DmxSide(C.Structure):

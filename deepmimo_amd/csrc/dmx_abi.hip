@@ -37,6 +37,7 @@ static int check_params(const dmx_params* p) {
         set_error("unknown radiation pattern id"); return DMX_ERR_ARG;
     }
     if (p->num_paths < 0) { set_error("num_paths must be >= 0"); return DMX_ERR_ARG; }
+    if ((p->flags & ~DMX_FLAG_ADAPTIVE_TERMS) != 0 || p->reserved0 != 0) { set_error("unknown bits in dmx_params.flags / reserved0"); return DMX_ERR_ARG; }
     if (p->freq_domain) {
         if (p->n_subcarriers < 1) { set_error("ofdm.subcarriers must be >= 1"); return DMX_ERR_ARG; }
         if (p->n_selected < 0 || (p->n_selected > 0 && !p->selected_subcarriers)) {

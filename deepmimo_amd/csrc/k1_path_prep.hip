@@ -357,7 +357,9 @@ int launch_path_prep(const dmx_rays& rays, const dmx_params& prm, const WsView& 
     a.P = ws.P; a.freq_domain = prm.freq_domain; a.n_sc = prm.n_subcarriers;
     a.ts32 = (float)(1.0 / prm.bandwidth);
     a.doppler = prm.enable_doppler; a.fc = prm.carrier_freq; a.rx_filter = prm.rx_filter && prm.freq_domain;
-    a.sort_paths = prm.freq_domain ? 1 : 0;                // the time-domain slots keep the path order (channel.py:285-287)
+    // amplitude order only where something uses it: the opt-in adaptive precision of stage 2 (frequency domain; the
+    // time-domain slots keep the path order, channel.py:285-287).  25 lane shuffles per user otherwise saved.
+    a.sort_paths = (prm.freq_domain && (prm.flags & DMX_FLAG_ADAPTIVE_TERMS)) ? 1 : 0;
     a.need_angles = prm.fov_enabled || prm.bs_pattern != DMX_PATTERN_ISOTROPIC || prm.ue_pattern != DMX_PATTERN_ISOTROPIC ||
                     side.aod_el_rot || side.aod_az_rot || side.aoa_el_rot || side.aoa_az_rot;
     if (rays.n_ue == 0) return DMX_OK;

@@ -25,9 +25,7 @@
 // splits per K-step), 3 MFMAs per K-step, 16 non-temporal buffer_store_dword (two 128-B row segments each; the row
 // offsets come from a table because row (a,p) lives at (p*K + 16a)*8 bytes).  Persistent grid.
 #include "dmx_common.h"
-#include <stdlib.h>
-// see DMX_MFMA_RESULT_GUARD in k2_mfma_frag.h (this file does not include it)
-#define FOLD_TILE_GUARD asm volatile("s_nop 3")
+#include "dmx_tuning.h"
 
 namespace dmx {
 
@@ -35,11 +33,16 @@ typedef _Float16 fh8 __attribute__((ext_vector_type(8)));
 typedef _Float16 fh2 __attribute__((ext_vector_type(2)));
 typedef __fp16 fhp2 __attribute__((ext_vector_type(2)));
 typedef float ff16 __attribute__((ext_vector_type(16)));
+typedef unsigned fu4 __attribute__((ext_vector_type(4)));
 
 static constexpr int FOLD_TROW = 272;            // bytes per table row: 32 complex64 + 16 B pad (conflict-free ds_read_b128)
 static constexpr float FOLD_B_SCALE = 64.0f;     // 2^6 on the unit-modulus E2' operand
 static constexpr int FOLD_MAX_M = 128;          // u8 element indices, rowsrc packing (128 x 272 < 65536)
 static constexpr int FOLD_SHARED_FROM = 33;     // antenna pairs from which the four waves of a workgroup share one set of tables
+// LDS a workgroup asks for at least: 5 x this exceeds the 160 KiB of a CU, so at most FOUR workgroups (four waves per
+// SIMD) are ever resident.  Every non-reproducible build of round 2 ran at five; the
+// register count alone (tests/test_isa_lint.py) must not be what keeps the kernel out of that regime.
+static constexpr size_t FOLD_MIN_LDS = 160 * 1024 / 5 + 64;
 
 struct FoldArgs {
     int64_t user_begin;
@@ -54,15 +57,16 @@ struct FoldArgs {
     int nsuper;        // ceil(nblk / sch): work items per user
     int nb_last;       // blocks of the last inner chunk
     int tab_rows;      // rows of the row tables (multiple of 32)
-    int adaptive;      // 1 = a weak last K-step may take one product term
+    int adaptive;      // 1 = a weak last K-step may take one product term (dmx_params.flags & DMX_FLAG_ADAPTIVE_TERMS)
     int k_tail;        // K - 16*(nblk-1): valid subcarriers of the last block (1..16)
+    int mlog;          // log2(M) when M is a power of two (row offsets of the stores are then scalar arithmetic), else -1
 };
 
 typedef float fv2 __attribute__((ext_vector_type(2)));
 
-// x = hi + lo in f16.  The residual x - hi is ONE mixed-precision fma per value (v_fma_mix_f32 reads the f16 half of the
-// packed register in place) - selected by the compiler from fma(f16 -> f32, m1, x) with m1 = WsView::neg_one; see k2_mfma_frag.h for why
-// this is no longer inline asm.
+// x = hi + lo in f16 (B' fragments, once per user).  The residual x - hi is ONE mixed-precision fma per value
+// (v_fma_mix_f32 reads the f16 half of the packed register in place), selected by the compiler from
+// fma(f16 -> f32, m1, x) with m1 = WsView::neg_one (k2_mfma_frag.h).
 __device__ __forceinline__ void fold_split2(float x0, float x1, fh2& hi, fh2& lo, float m1) {
     const fhp2 h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
     const fh2 hh = __builtin_bit_cast(fh2, h);
@@ -76,12 +80,6 @@ __device__ __forceinline__ void fold_split2(float x0, float x1, fh2& hi, fh2& lo
 // float -> its bits, by VALUE: __builtin_bit_cast applied directly to a vector-element lvalue (`bit_cast(unsigned, v[i])`)
 // reads element 0 whatever i is with this compiler; through a by-value parameter it is the element asked for
 __device__ __forceinline__ unsigned fold_bits(float x) { return __builtin_bit_cast(unsigned, x); }
-
-// (a + jb)(c + jd) as two packed instructions: [ac, ad] then fma([-b, b], [d, c], .)
-__device__ __forceinline__ fv2 fold_cmul(float a, float b, float c, float d) {
-    const fv2 t = fv2{a, a} * fv2{c, d};
-    return __builtin_elementwise_fma(fv2{-b, b}, fv2{d, c}, t);
-}
 
 // a wave's own LDS writes are visible to its later reads (DS operations of one wave execute in order); the compiler
 // only has to be kept from moving accesses across this point
@@ -101,114 +99,288 @@ __device__ __forceinline__ void fold_sync() {
     else wave_lds_sync();
 }
 
-// One 32-row tile (a,p) x 32 columns: NS K-steps of A' = Ac[p][l] E1[a][l] (complex products, then the f16 hi / lo split)
-// against the item's E2' fragments, and the un-scaling of the accumulator.  NS and LW (weak last K-step: A'hi B'hi only,
-// no A'lo built) are template parameters, each K-step's MFMAs are fenced with sched_barrier, the choice of (NS, LW) is made
-// OUTSIDE the tile loop (fold_tiles below), and even / odd K-steps accumulate into two different accumulators - all on
-// purpose.  Round 2 went through four builds of this loop that were not bit-reproducible: two identical launches differed
-// in accumulator registers 8..15 of one tile (the ones an MFMA writes in its last passes; 16 subcarriers x the tile's
-// second 16 rows), by 5e-4 ... 1e-1 of the user's peak - for 1 user in 200 (K-steps guarded at run time with the adaptive
-// branch inside; or the scheduler threading the next A' split between a K-step's MFMAs), for 1 user-launch in 10^7 on
-// every box (a per-tile switch that the compiler merged into shared blocks), and for 1 in 10^7...10^9 on SOME boxes of the
-// pool only (one accumulator, everything else as now).  Every parity test on a few hundred users stayed green throughout.
-// What the failing builds share: an MFMA that accumulates onto the result of an MFMA issued roughly one MFMA-group
-// duration earlier (32 ... 120 cycles), i.e. whose SrcC is being written back right when it is picked up; builds that moved
-// dependent MFMAs towards that distance failed more often (four hidden wait states behind every K-step's group: 1,000 x
-// more), builds that moved them away less.  Direct probes on boxes of unknown susceptibility show nothing of it
-// (tools/mfma_*_probe.hip: sources latched at issue, dependent MFMAs correct at every tested distance, 12 wait states for
-// the last accumulator register).  With two accumulators an MFMA only ever accumulates back to back onto its own K-step or
-// onto a K-step two steps back: on a box where the one-accumulator build differed in 14 of 600 million user-launches this
-// one differed in 0 of 1.4 billion (tools/hot_box_hunt.sh).  tests/test_gpu_parity.py::test_launches_are_bit_reproducible
-// and the stress tests in tests/test_gpu_fullsize.py guard it; tools/repro_stress.py is the long form.
-template <int NS, bool LW>
-__device__ __forceinline__ ff16 fold_tile(const unsigned char* arow, const unsigned char* erow, const fh8 (&Bhi)[4],
-                                          const fh8 (&Blo)[4], float m1, float oscale) {
-    // TWO accumulators, even and odd K-steps: an MFMA then never accumulates onto the result of the K-step just before it,
-    // only onto the one two steps back, long finished.  With one accumulator the first MFMA of K-step s + 1 was issued about
-    // one K-step's A' construction (~120 cycles) behind the three MFMAs of K-step s (96 cycles of matrix pipe) - right around
-    // the moment their last pass wrote accumulator registers 8..15 - and on some boxes of the pool, once in 10^7...10^9
-    // users, those registers went into the next MFMA without the last contribution (every build that
-    // moved dependent MFMAs towards that distance failed more often, the ones that moved them away less).
-    ff16 acc[2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const float4 x0 = *reinterpret_cast<const float4*>(arow + s * 64);
-        const float4 x1 = *reinterpret_cast<const float4*>(arow + s * 64 + 16);
-        const float4 y0 = *reinterpret_cast<const float4*>(erow + s * 64);
-        const float4 y1 = *reinterpret_cast<const float4*>(erow + s * 64 + 16);
-        const fv2 z0 = fold_cmul(x0.x, x0.y, y0.x, y0.y), z1 = fold_cmul(x0.z, x0.w, y0.z, y0.w);
-        const fv2 z2 = fold_cmul(x1.x, x1.y, y1.x, y1.y), z3 = fold_cmul(x1.z, x1.w, y1.z, y1.w);
-        fh8 Ah;
-        if (LW && s == NS - 1) {
-            const fh2 p0 = __builtin_bit_cast(fh2, __builtin_amdgcn_cvt_pkrtz(z0[0], z0[1]));
-            const fh2 p1 = __builtin_bit_cast(fh2, __builtin_amdgcn_cvt_pkrtz(z1[0], z1[1]));
-            const fh2 p2 = __builtin_bit_cast(fh2, __builtin_amdgcn_cvt_pkrtz(z2[0], z2[1]));
-            const fh2 p3 = __builtin_bit_cast(fh2, __builtin_amdgcn_cvt_pkrtz(z3[0], z3[1]));
-            Ah[0] = p0[0]; Ah[1] = p0[1]; Ah[2] = p1[0]; Ah[3] = p1[1]; Ah[4] = p2[0]; Ah[5] = p2[1]; Ah[6] = p3[0]; Ah[7] = p3[1];
-            __builtin_amdgcn_sched_barrier(0);
-            acc[s & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bhi[s], acc[s & 1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
-            fh8 Al;
-            fh2 ph, pl;
-            fold_split2(z0[0], z0[1], ph, pl, m1);
-            Ah[0] = ph[0]; Ah[1] = ph[1]; Al[0] = pl[0]; Al[1] = pl[1];
-            fold_split2(z1[0], z1[1], ph, pl, m1);
-            Ah[2] = ph[0]; Ah[3] = ph[1]; Al[2] = pl[0]; Al[3] = pl[1];
-            fold_split2(z2[0], z2[1], ph, pl, m1);
-            Ah[4] = ph[0]; Ah[5] = ph[1]; Al[4] = pl[0]; Al[5] = pl[1];
-            fold_split2(z3[0], z3[1], ph, pl, m1);
-            Ah[6] = ph[0]; Ah[7] = ph[1]; Al[6] = pl[0]; Al[7] = pl[1];
-            // the three MFMAs of a K-step stay together, back to back (dependent MFMAs issued back to back are the path
-            // every GEMM kernel exercises), nothing scheduled between or right behind them
-            __builtin_amdgcn_sched_barrier(0);
-            acc[s & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bhi[s], acc[s & 1], 0, 0, 0);
-            acc[s & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Blo[s], acc[s & 1], 0, 0, 0);
-            acc[s & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bhi[s], acc[s & 1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    FOLD_TILE_GUARD;
-    ff16 out;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) out[i] = (NS > 1 ? acc[0][i] + acc[1][i] : acc[0][i]) * oscale;
-    return out;
+// ---------------------------------------------------------------------------------------------------------------------
+// The tile loop.  Round 2 went through four builds of it that were not bit-reproducible (two identical launches differed
+// in rows 16..31 of one 32-row tile, 5e-4 ... 1e-1 of the user's peak, once per 200 ... 10^9 users; DESIGN.md section 4 has
+// the table of those builds' machine code, tools/isa_incident_table.py regenerates it).  The cause was never pinned to one
+// instruction pair, so this loop is written so that NONE of the candidate mechanisms can occur, and
+// tests/test_isa_lint.py checks the built code object for each of them:
+//   * result read: the accumulators pass through `s_nop 15` (16 wait states; the hazard table's - and the probe's - 12
+//     plus 4) as operands of the asm statement, so no read can be scheduled in front of it, and everything that reads
+//     them is ordered behind it by data dependence;
+//   * operands of an issued MFMA: the loads of the NEXT K-step (or the next tile's first) are issued BEFORE a K-step's
+//     MFMAs, into registers of their own (v[112:127], by name), and the first vector instruction that can write a
+//     register of a K-step's A' operands is the tenth of the next K-step's statement (a wait and eight products first);
+//     the row-offset table is read only behind the result guard;
+//   * accumulation chains: even and odd K-steps run into two accumulators, so an MFMA group accumulates onto the group
+//     two K-steps back (>= 50 wait states), never onto the one just issued (the failing builds: dependent groups 27-43
+//     wait states apart on one accumulator; this arrangement did not differ in 1.4e9 user-launches on a box where the
+//     one-accumulator build differed 14 times in 6e8);
+//   * residency: at most four waves per SIMD (FOLD_MIN_LDS): all failing builds ran at five.
+// The vector work of a K-step and of the epilogue is `asm volatile`: the compiler allocates the registers, but the order
+// is the one written here - no dependent pair is adjacent and nothing of a later K-step is threaded between the MFMAs.
+
+// One K-step of a lane's table rows - 4 entries of Ac[p][.] (x0, x1) and of E1[a][.] (y0, y1), 16 registers - lives in
+// v[112:127] BY NAME: the asm statements below load, multiply and split it in place (the halves of a 64-bit product
+// cannot be named through an operand), and the variables are tied to those registers at every statement so that the
+// compiler keeps them free in between.  v[108:111] are scratch inside a statement (clobbers).  The kernel is compiled
+// for 128 registers (__launch_bounds__(256, 4)).
+typedef float ff4 __attribute__((ext_vector_type(4)));
+struct FoldX { ff4 x0, x1, y0, y1; };
+#define FOLD_X_IO(X) "+{v[112:115]}"((X).x0), "+{v[116:119]}"((X).x1), "+{v[120:123]}"((X).y0), "+{v[124:127]}"((X).y1)
+
+// LDS byte address (the DS instructions' operand) of a pointer into the dynamic shared memory
+__device__ __forceinline__ uint32_t fold_lds_addr(const void* p) {
+    return (uint32_t)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
 
-// The row tiles of one inner chunk for a fixed (NS, LW): tile body (fold_tile) and its 16 stores.
-template <bool NT, int WS, int NS, bool LW>
+// the first K-step of a tile sequence: loads only
+__device__ __forceinline__ void fold_load0(FoldX& X, uint32_t ar, uint32_t er) {
+    asm volatile(
+        "ds_read_b128 v[112:115], %4\n\t"
+        "ds_read_b128 v[116:119], %4 offset:16\n\t"
+        "ds_read_b128 v[120:123], %5\n\t"
+        "ds_read_b128 v[124:127], %5 offset:16"
+        : "={v[112:115]}"(X.x0), "={v[116:119]}"(X.x1), "={v[120:123]}"(X.y0), "={v[124:127]}"(X.y1)
+        : "v"(ar), "v"(er));
+}
+
+// the loads of the last statement have landed (the compiler does not count a statement's memory operations)
+__device__ __forceinline__ void fold_drain(FoldX& X) { asm volatile("s_waitcnt lgkmcnt(0)" : FOLD_X_IO(X)); }
+
+// One K-step: wait for its table entries, A'[(a,p)][l] = Ac[p][l] E1[a][l] for the lane's four paths in place, the f16
+// hi / lo split, and the loads of the NEXT K-step (rows at ar / er, byte offset OFF) - 24 vector instructions (8 packed
+// complex-product halves, 4 + 4 conversions, 8 residuals), no moves, no padding, in ONE statement.  (One instruction per
+// statement: the hazard recognizer pads every statement that reads what the statement right in front of it wrote, 4
+// s_nop per K-step.)  Inside the statement no instruction reads the result of the one before it.
+// (a + jb)(c + jd): u = (b d, b c), then z = (a c - u.x, a d + u.y).
+#define FOLD_CMUL_TEXT                                                                                               \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                       \
+    "v_pk_mul_f32 v[108:109], v[112:113], v[120:121] op_sel:[1,1] op_sel_hi:[1,0]\n\t"                                \
+    "v_pk_mul_f32 v[110:111], v[114:115], v[122:123] op_sel:[1,1] op_sel_hi:[1,0]\n\t"                                \
+    "v_pk_fma_f32 v[112:113], v[112:113], v[120:121], v[108:109] op_sel_hi:[0,1,1] neg_lo:[0,0,1]\n\t"                \
+    "v_pk_fma_f32 v[114:115], v[114:115], v[122:123], v[110:111] op_sel_hi:[0,1,1] neg_lo:[0,0,1]\n\t"                \
+    "v_pk_mul_f32 v[108:109], v[116:117], v[124:125] op_sel:[1,1] op_sel_hi:[1,0]\n\t"                                \
+    "v_pk_mul_f32 v[110:111], v[118:119], v[126:127] op_sel:[1,1] op_sel_hi:[1,0]\n\t"                                \
+    "v_pk_fma_f32 v[116:117], v[116:117], v[124:125], v[108:109] op_sel_hi:[0,1,1] neg_lo:[0,0,1]\n\t"                \
+    "v_pk_fma_f32 v[118:119], v[118:119], v[126:127], v[110:111] op_sel_hi:[0,1,1] neg_lo:[0,0,1]\n\t"
+#define FOLD_CVT_HI_TEXT                                                                                             \
+    "v_cvt_pkrtz_f16_f32 %0, v112, v113\n\t"                                                                         \
+    "v_cvt_pkrtz_f16_f32 %1, v114, v115\n\t"                                                                         \
+    "v_cvt_pkrtz_f16_f32 %2, v116, v117\n\t"                                                                         \
+    "v_cvt_pkrtz_f16_f32 %3, v118, v119\n\t"
+template <bool LO, int OFF>
+__device__ __forceinline__ void fold_kstep(FoldX& X, float m1, uint32_t ar, uint32_t er, fh8& Ah, fh8& Al) {
+    unsigned h0, h1, h2, h3;
+    if constexpr (LO) {
+        unsigned l0, l1, l2, l3;
+        asm volatile(
+            FOLD_CMUL_TEXT
+            FOLD_CVT_HI_TEXT
+            "v_fma_mix_f32 v112, %0, %14, v112 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 v113, %0, %14, v113 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 v114, %1, %14, v114 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 v115, %1, %14, v115 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 v116, %2, %14, v116 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 v117, %2, %14, v117 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 v118, %3, %14, v118 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 v119, %3, %14, v119 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_cvt_pkrtz_f16_f32 %4, v112, v113\n\t"
+            "v_cvt_pkrtz_f16_f32 %5, v114, v115\n\t"
+            "v_cvt_pkrtz_f16_f32 %6, v116, v117\n\t"
+            "v_cvt_pkrtz_f16_f32 %7, v118, v119\n\t"
+            "ds_read_b128 v[112:115], %12 offset:%15\n\t"
+            "ds_read_b128 v[116:119], %12 offset:%16\n\t"
+            "ds_read_b128 v[120:123], %13 offset:%15\n\t"
+            "ds_read_b128 v[124:127], %13 offset:%16"
+            : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3), FOLD_X_IO(X)
+            : "v"(ar), "v"(er), "s"(m1), "i"(OFF), "i"(OFF + 16)
+            : "v108", "v109", "v110", "v111");
+        Al = __builtin_bit_cast(fh8, fu4{l0, l1, l2, l3});
+    } else {
+        asm volatile(
+            FOLD_CMUL_TEXT
+            FOLD_CVT_HI_TEXT
+            "ds_read_b128 v[112:115], %8 offset:%10\n\t"
+            "ds_read_b128 v[116:119], %8 offset:%11\n\t"
+            "ds_read_b128 v[120:123], %9 offset:%10\n\t"
+            "ds_read_b128 v[124:127], %9 offset:%11"
+            : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), FOLD_X_IO(X)
+            : "v"(ar), "v"(er), "i"(OFF), "i"(OFF + 16)
+            : "v108", "v109", "v110", "v111");
+    }
+    Ah = __builtin_bit_cast(fh8, fu4{h0, h1, h2, h3});
+    if constexpr (!LO) Al = Ah;                              // never used as an operand (weak last K-step)
+}
+#undef FOLD_CMUL_TEXT
+#undef FOLD_CVT_HI_TEXT
+
+// Byte offset, inside the chunk's output window, of the row whose index bits are `r` (r = a * M + p for M = 2^mlog):
+// (p K + 16 a) * 8.  The row index of accumulator register i in tile rt is 32 rt + (i & 3) + 8 (i >> 2) + 4 (lane >> 5):
+// the four terms occupy disjoint bits, so the offset is the SUM of four terms' offsets - a per-tile scalar, two sets of
+// four kernel constants, and a per-lane constant.
+__device__ __forceinline__ uint32_t fold_rowbits_off(uint32_t r, int mlog, uint32_t K8) {
+    return (r & ((1u << mlog) - 1u)) * K8 + ((r >> mlog) << 7);
+}
+
+// Un-scaled tile -> 16 stores.  The accumulators are read by asm statements only (behind the guard): the hazard
+// recognizer does not look into them, and it does not have to.
+template <int NS>
+__device__ __forceinline__ void fold_finish(ff16& acc0, ff16& acc1, fv2 osc, fv2 (&w)[8]) {
+    if constexpr (NS > 1) {
+        asm volatile("s_nop 15" : "+v"(acc0), "+v"(acc1));
+        fv2 t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const fv2 a = {acc0[2 * i], acc0[2 * i + 1]}, b = {acc1[2 * i], acc1[2 * i + 1]};
+            asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(t[i]) : "v"(a), "v"(b));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(w[i]) : "v"(t[i]), "v"(osc));
+    } else {
+        asm volatile("s_nop 15" : "+v"(acc0));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const fv2 a = {acc0[2 * i], acc0[2 * i + 1]};
+            asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(w[i]) : "v"(a), "v"(osc));
+        }
+    }
+}
+
+// K-steps S ... NS-1 of a tile (compile-time recursion: the byte offset of the next K-step's loads is an immediate of
+// the asm statement).  Even K-steps accumulate into acc0, odd ones into acc1.  Operands of K-step S, and the loads of
+// K-step S + 1 - of the next tile's first K-step after the last one (rows at arn / ern) - issued in front of its MFMAs.
+// (K-steps 0, 1 and 2, 3 as two back-to-back runs of six MFMAs - no dependent MFMA anywhere but right behind its
+// producer - was built too: two live operand sets need 16 registers more than the 128 of four waves per SIMD leave,
+// and the compiler then reloads a B' fragment from scratch between the MFMAs.)
+template <int S, int NS, bool LW>
+__device__ __forceinline__ void fold_ksteps(FoldX& X, float m1, uint32_t ar, uint32_t er, uint32_t arn, uint32_t ern,
+                                            ff16& acc0, ff16& acc1, const fh8 (&Bhi)[4], const fh8 (&Blo)[4]) {
+    constexpr bool weak = LW && S == NS - 1;
+    fh8 Ah, Al;
+    if constexpr (S == NS - 1) fold_kstep<!weak, 0>(X, m1, arn, ern, Ah, Al);
+    else fold_kstep<true, (S + 1) * 64>(X, m1, ar, er, Ah, Al);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (S & 1) {
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bhi[S], acc1, 0, 0, 0);
+        if constexpr (!weak) {
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Blo[S], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bhi[S], acc1, 0, 0, 0);
+        }
+    } else {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bhi[S], acc0, 0, 0, 0);
+        if constexpr (!weak) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Blo[S], acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bhi[S], acc0, 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (S + 1 < NS) fold_ksteps<S + 1, NS, LW>(X, m1, ar, er, arn, ern, acc0, acc1, Bhi, Blo);
+}
+
+struct FoldStoreCtx {
+    __amdgpu_buffer_rsrc_t orsrc;
+    uint32_t lane_col;         // byte offset of the lane's column inside a row segment
+    uint32_t lane_row;         // SROW: lane_col + the offset of the lane's half-wave row term (4 (lane >> 5))
+    uint32_t lmask_last;       // table path: lanes past K in a partial last block keep bit 31 of the row offset
+    uint32_t K8;               // K * 8
+    int mlog;
+    int nb;                    // blocks of this chunk
+    int lane_hh;               // lane >> 5
+    int tail_lane_dead;        // this lane's subcarrier is past K in the partial last block
+    bool masked;               // the chunk ends with a partial last block
+};
+
+// The row tiles of one inner chunk for a fixed (NS, LW).  SROW: M is a power of two and the 16 row offsets of a tile are
+// scalar arithmetic (no table read, no vector add per store); tiles that hold rows past the chunk or the partial last
+// block take the checked form at the end.  Otherwise the offsets come from the row table, read behind the result guard.
+template <bool NT, int WS, int NS, bool LW, bool SROW>
 __device__ __forceinline__ void fold_tiles(int sub, int ntiles, const uint32_t* rowsrc, const uint32_t* rowoff, int lp, int hh,
                                            const unsigned char* Ac, const unsigned char* E1, const fh8 (&Bhi)[4], const fh8 (&Blo)[4],
-                                           float m1, float oscale, bool masked, __amdgpu_buffer_rsrc_t orsrc, uint32_t lane_col,
-                                           uint32_t lmask_last) {
+                                           float m1, fv2 osc, const FoldStoreCtx& c) {
+    if (sub >= ntiles) return;
+    constexpr int AUX = NT ? 2 : 0;
+    // first tile that needs per-row checks (SROW): the one holding the last block when that block is partial, else the
+    // last tile when the chunk's rows do not fill it
+    const int rows = c.nb << (SROW ? c.mlog : 0);
+    const int rt_chk = !SROW ? 0 : (c.masked ? (((c.nb - 1) << c.mlog) >> 5) : ((rows & 31) ? ntiles - 1 : ntiles));
+    uint32_t P[4], D[4];
+    if constexpr (SROW) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { P[q] = fold_rowbits_off((uint32_t)q, c.mlog, c.K8); D[q] = fold_rowbits_off((uint32_t)(8 * q), c.mlog, c.K8); }
+    }
+    const uint32_t ac_lds = fold_lds_addr(Ac) + (uint32_t)hh * 32u, e1_lds = fold_lds_addr(E1) + (uint32_t)hh * 32u;
+    uint32_t src = rowsrc[(sub << 5) + lp];
+    uint32_t ar = ac_lds + (src >> 16), er = e1_lds + (src & 0xFFFFu);
+    FoldX X;
+    fold_load0(X, ar, er);
     for (int rt = sub; rt < ntiles; rt += WS) {
-        const uint32_t src = rowsrc[(rt << 5) + lp];
-        const unsigned char* arow = Ac + (src >> 16) + hh * 32;
-        const unsigned char* erow = E1 + (src & 0xFFFFu) + hh * 32;
-        // the tile, un-scaled: register i is row (i&3) + 8*(i>>2) + 4*(lane>>5), column lane&31
-        const ff16 sv = fold_tile<NS, LW>(arow, erow, Bhi, Blo, m1, oscale);
-        const uint4* ro4 = reinterpret_cast<const uint4*>(rowoff + (rt << 5) + 4 * hh);
-        if (masked) {                                                  // wave-uniform: partial last block in this item
+        const int rtn = rt + WS < ntiles ? rt + WS : rt;                // past the end: the same rows again (never used)
+        const uint32_t srcn = rowsrc[(rtn << 5) + lp];
+        const uint32_t arn = ac_lds + (srcn >> 16), ern = e1_lds + (srcn & 0xFFFFu);
+        ff16 acc0, acc1;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const uint4 ro = ro4[2 * g];
-                __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 0]), orsrc, lane_col + (ro.x & lmask_last), 0, NT ? 2 : 0);
-                __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 1]), orsrc, lane_col + (ro.y & lmask_last), 0, NT ? 2 : 0);
-                __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 2]), orsrc, lane_col + (ro.z & lmask_last), 0, NT ? 2 : 0);
-                __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 3]), orsrc, lane_col + (ro.w & lmask_last), 0, NT ? 2 : 0);
+        for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+        fold_ksteps<0, NS, LW>(X, m1, ar, er, arn, ern, acc0, acc1, Bhi, Blo);
+        ar = arn; er = ern;
+        fv2 w[8];
+        fold_finish<NS>(acc0, acc1, osc, w);
+        // register i of the tile is row (i & 3) + 8 (i >> 2) + 4 (lane >> 5), column lane & 31
+        if constexpr (SROW) {
+            const uint32_t T = fold_rowbits_off((uint32_t)rt << 5, c.mlog, c.K8);
+            if (rt < rt_chk) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    __builtin_amdgcn_raw_buffer_store_b32(fold_bits(w[i >> 1][i & 1]), c.orsrc, c.lane_row, T + P[i & 3] + D[i >> 2], AUX);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int a_blk = ((rt << 5) + (i & 3) + 8 * (i >> 2) + 4 * c.lane_hh) >> c.mlog;
+                    const bool dead = a_blk >= c.nb || (c.masked && a_blk == c.nb - 1 && c.tail_lane_dead);
+                    __builtin_amdgcn_raw_buffer_store_b32(fold_bits(w[i >> 1][i & 1]), c.orsrc, dead ? 0x80000000u : c.lane_row,
+                                                          T + P[i & 3] + D[i >> 2], AUX);
+                }
             }
-        } else {                                                       // rows past the item carry 0xC0000000: out of range as they are
+        } else {
+            const uint4* ro4 = reinterpret_cast<const uint4*>(rowoff + (rt << 5) + 4 * hh);
+            if (c.masked) {                                            // wave-uniform: partial last block in this chunk
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const uint4 ro = ro4[2 * g];
-                __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 0]), orsrc, lane_col + ro.x, 0, NT ? 2 : 0);
-                __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 1]), orsrc, lane_col + ro.y, 0, NT ? 2 : 0);
-                __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 2]), orsrc, lane_col + ro.z, 0, NT ? 2 : 0);
-                __builtin_amdgcn_raw_buffer_store_b32(fold_bits(sv[4 * g + 3]), orsrc, lane_col + ro.w, 0, NT ? 2 : 0);
+                for (int g = 0; g < 4; ++g) {
+                    const uint4 ro = ro4[2 * g];
+                    __builtin_amdgcn_raw_buffer_store_b32(fold_bits(w[2 * g][0]), c.orsrc, c.lane_col + (ro.x & c.lmask_last), 0, AUX);
+                    __builtin_amdgcn_raw_buffer_store_b32(fold_bits(w[2 * g][1]), c.orsrc, c.lane_col + (ro.y & c.lmask_last), 0, AUX);
+                    __builtin_amdgcn_raw_buffer_store_b32(fold_bits(w[2 * g + 1][0]), c.orsrc, c.lane_col + (ro.z & c.lmask_last), 0, AUX);
+                    __builtin_amdgcn_raw_buffer_store_b32(fold_bits(w[2 * g + 1][1]), c.orsrc, c.lane_col + (ro.w & c.lmask_last), 0, AUX);
+                }
+            } else {                                                   // rows past the item carry 0xC0000000: out of range as they are
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint4 ro = ro4[2 * g];
+                    __builtin_amdgcn_raw_buffer_store_b32(fold_bits(w[2 * g][0]), c.orsrc, c.lane_col + ro.x, 0, AUX);
+                    __builtin_amdgcn_raw_buffer_store_b32(fold_bits(w[2 * g][1]), c.orsrc, c.lane_col + ro.y, 0, AUX);
+                    __builtin_amdgcn_raw_buffer_store_b32(fold_bits(w[2 * g + 1][0]), c.orsrc, c.lane_col + ro.z, 0, AUX);
+                    __builtin_amdgcn_raw_buffer_store_b32(fold_bits(w[2 * g + 1][1]), c.orsrc, c.lane_col + ro.w, 0, AUX);
+                }
             }
         }
+    }
+    fold_drain(X);                                                      // the last statement's loads (never used) have landed
+}
+
+// one loop nest per (K-steps, weak last step): the choice is made out here, so that inside a loop every tile is the same
+// straight-line code from its first LDS read to its last store
+template <bool NT, int WS, bool SROW>
+__device__ __forceinline__ void fold_tiles_kind(int tile_kind, int sub, int ntiles, const uint32_t* rowsrc, const uint32_t* rowoff, int lp, int hh,
+                                                const unsigned char* Ac, const unsigned char* E1, const fh8 (&Bhi)[4], const fh8 (&Blo)[4],
+                                                float m1, fv2 osc, const FoldStoreCtx& c) {
+    switch (tile_kind) {
+        case 2: fold_tiles<NT, WS, 1, false, SROW>(sub, ntiles, rowsrc, rowoff, lp, hh, Ac, E1, Bhi, Blo, m1, osc, c); break;
+        case 4: fold_tiles<NT, WS, 2, false, SROW>(sub, ntiles, rowsrc, rowoff, lp, hh, Ac, E1, Bhi, Blo, m1, osc, c); break;
+        case 5: fold_tiles<NT, WS, 2, true, SROW>(sub, ntiles, rowsrc, rowoff, lp, hh, Ac, E1, Bhi, Blo, m1, osc, c); break;
+        case 6: fold_tiles<NT, WS, 3, false, SROW>(sub, ntiles, rowsrc, rowoff, lp, hh, Ac, E1, Bhi, Blo, m1, osc, c); break;
+        case 7: fold_tiles<NT, WS, 3, true, SROW>(sub, ntiles, rowsrc, rowoff, lp, hh, Ac, E1, Bhi, Blo, m1, osc, c); break;
+        case 8: fold_tiles<NT, WS, 4, false, SROW>(sub, ntiles, rowsrc, rowoff, lp, hh, Ac, E1, Bhi, Blo, m1, osc, c); break;
+        default: fold_tiles<NT, WS, 4, true, SROW>(sub, ntiles, rowsrc, rowoff, lp, hh, Ac, E1, Bhi, Blo, m1, osc, c); break;
     }
 }
 
@@ -300,6 +472,7 @@ __global__ __launch_bounds__(256, 4) void k2_fd_fold(WsView ws, FoldArgs a, floa
         (void)frexpf(m, &e);                                               // m = f * 2^e, f in [0.5, 1)
         const float gs = ldexpf(1.0f, 10 - e);                             // max |c| component -> [512, 1024)
         const float oscale = ldexpf(1.0f, e - 10 - 6);                     // 1 / (gs * FOLD_B_SCALE)
+        const fv2 osc = {oscale, oscale};
         const double qh = rint(q * 4096.0) * (1.0 / 4096.0);
         const float qhf = (float)qh, qlf = (float)(q - qh);
         const float cgr = cr * gs, cgi = ci * gs;
@@ -363,22 +536,21 @@ __global__ __launch_bounds__(256, 4) void k2_fd_fold(WsView ws, FoldArgs a, floa
 
         // ---- row tiles: 32 rows (a,p) each
         const uint32_t* rowoff = last ? rowoff1 : rowoff0;
-        const bool masked = last && a.k_tail < 16;
         const int rows = nb * M;
         const int ntiles = (rows + 31) >> 5;
-        const __amdgpu_buffer_rsrc_t orsrc =
-            __builtin_amdgcn_make_buffer_rsrc(o, 0, (int)((unsigned)(user_floats - (size_t)a0 * 32) * 4u), 0x00020000);
-        // one loop nest per (K-steps, weak last step): the choice is made out here, so that inside a loop every tile is
-        // the same straight-line code from its first LDS read to its last store
-        switch (tile_kind) {
-            case 2: fold_tiles<NT, WS, 1, false>(sub, ntiles, rowsrc, rowoff, lp, hh, Ac, E1, Bhi, Blo, ws.neg_one, oscale, masked, orsrc, lane_col, lmask_last); break;
-            case 4: fold_tiles<NT, WS, 2, false>(sub, ntiles, rowsrc, rowoff, lp, hh, Ac, E1, Bhi, Blo, ws.neg_one, oscale, masked, orsrc, lane_col, lmask_last); break;
-            case 5: fold_tiles<NT, WS, 2, true>(sub, ntiles, rowsrc, rowoff, lp, hh, Ac, E1, Bhi, Blo, ws.neg_one, oscale, masked, orsrc, lane_col, lmask_last); break;
-            case 6: fold_tiles<NT, WS, 3, false>(sub, ntiles, rowsrc, rowoff, lp, hh, Ac, E1, Bhi, Blo, ws.neg_one, oscale, masked, orsrc, lane_col, lmask_last); break;
-            case 7: fold_tiles<NT, WS, 3, true>(sub, ntiles, rowsrc, rowoff, lp, hh, Ac, E1, Bhi, Blo, ws.neg_one, oscale, masked, orsrc, lane_col, lmask_last); break;
-            case 8: fold_tiles<NT, WS, 4, false>(sub, ntiles, rowsrc, rowoff, lp, hh, Ac, E1, Bhi, Blo, ws.neg_one, oscale, masked, orsrc, lane_col, lmask_last); break;
-            default: fold_tiles<NT, WS, 4, true>(sub, ntiles, rowsrc, rowoff, lp, hh, Ac, E1, Bhi, Blo, ws.neg_one, oscale, masked, orsrc, lane_col, lmask_last); break;
-        }
+        FoldStoreCtx sc_;
+        sc_.orsrc = __builtin_amdgcn_make_buffer_rsrc(o, 0, (int)((unsigned)(user_floats - (size_t)a0 * 32) * 4u), 0x00020000);
+        sc_.lane_col = lane_col;
+        sc_.K8 = (uint32_t)K * 8u;
+        sc_.mlog = a.mlog;
+        sc_.lane_row = lane_col + (a.mlog >= 0 ? (uint32_t)hh * fold_rowbits_off(4u, a.mlog, (uint32_t)K * 8u) : 0u);
+        sc_.lmask_last = lmask_last;
+        sc_.nb = nb;
+        sc_.lane_hh = hh;
+        sc_.tail_lane_dead = bsc >= a.k_tail;
+        sc_.masked = last && a.k_tail < 16;
+        if (a.mlog >= 0) fold_tiles_kind<NT, WS, true>(tile_kind, sub, ntiles, rowsrc, rowoff, lp, hh, Ac, E1, Bhi, Blo, ws.neg_one, osc, sc_);
+        else fold_tiles_kind<NT, WS, false>(tile_kind, sub, ntiles, rowsrc, rowoff, lp, hh, Ac, E1, Bhi, Blo, ws.neg_one, osc, sc_);
         }                                                                  // inner chunks
     }
 }
@@ -450,15 +622,14 @@ int launch_channels_fd_fold(const dmx_params& prm, const WsView& ws, int64_t use
     a.sc_stride = prm.sc_stride;
     a.inv_n = 1.0 / (double)prm.n_subcarriers;
     a.nblk = (a.K + 15) / 16;
-    if (chunk_blocks <= 0) {                       // measurement hook: DMX_FOLD_CHUNK=8|16|32 overrides the LDS-occupancy rule
-        const char* env = getenv("DMX_FOLD_CHUNK");
-        if (env) chunk_blocks = atoi(env);
+    if (chunk_blocks <= 0) {                       // tuning build only: DMX_FOLD_CHUNK=8|16|32 overrides the LDS-occupancy rule
+        chunk_blocks = tuning_int("DMX_FOLD_CHUNK", 0);
         if (chunk_blocks != 8 && chunk_blocks != 16 && chunk_blocks != 32) chunk_blocks = 0;
     }
-    // table sets per workgroup: one per wave up to 32 pairs, one for the whole workgroup above (measurement hook
+    // table sets per workgroup: one per wave up to 32 pairs, one for the whole workgroup above (tuning build only:
     // DMX_FOLD_SHARED=0|1 forces either)
     bool shared = a.M >= FOLD_SHARED_FROM;
-    if (const char* env = getenv("DMX_FOLD_SHARED")) shared = env[0] == '1';
+    if (const int f = tuning_int("DMX_FOLD_SHARED", -1); f >= 0) shared = f == 1;
     const int sets = shared ? 1 : 4;
     a.ch = fold_chunk_blocks(a.M, a.nblk, chunk_blocks, sets);
     a.sch = (FOLD_SUPER / a.ch) * a.ch;
@@ -468,10 +639,14 @@ int launch_channels_fd_fold(const dmx_params& prm, const WsView& ws, int64_t use
     a.nb_last = a.nblk - a.ch * (a.nchunk - 1);
     a.tab_rows = (a.M * a.ch + 31) / 32 * 32;
     a.k_tail = a.K - 16 * (a.nblk - 1);
-    a.adaptive = getenv("DMX_NO_ADAPTIVE") == nullptr;              // env = measurement hook: always three terms
+    a.adaptive = (prm.flags & DMX_FLAG_ADAPTIVE_TERMS) ? 1 : 0;     // default: three product terms everywhere
+    a.mlog = -1;
+    for (int b = 0; b < 8; ++b) if (a.M == (1 << b)) a.mlog = b;
+    if (tuning_int("DMX_FOLD_ROWTABLE", 0) == 1) a.mlog = -1;       // tuning build only: force the row-table stores
     if ((size_t)a.M * (size_t)a.K * 8 >= (size_t)1 << 30) { set_error("%d x %d outputs per user are too many for the folded kernel", a.M, a.K); return DMX_ERR_SHAPE; }
-    const size_t smem = fold_static_bytes(a.tab_rows, a.M) + sets * fold_wave_bytes(a.M, a.ch);
+    size_t smem = fold_static_bytes(a.tab_rows, a.M) + sets * fold_wave_bytes(a.M, a.ch);
     if (smem > 160 * 1024) { set_error("folded kernel tables of %zu bytes exceed LDS", smem); return DMX_ERR_SHAPE; }
+    if (smem < FOLD_MIN_LDS) smem = FOLD_MIN_LDS;                   // at most four workgroups per CU (see FOLD_MIN_LDS)
     const int64_t items = user_count * a.nsuper;
     const void* kfn = shared ? reinterpret_cast<const void*>(k2_fd_fold<true, 4>) : reinterpret_cast<const void*>(k2_fd_fold<true, 1>);
     if (smem > 64 * 1024) {

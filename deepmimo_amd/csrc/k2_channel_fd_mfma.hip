@@ -29,6 +29,7 @@
 //            a scalar offset of the buffer instruction, so the epilogue is 1 VALU op per store.
 // HBM traffic = the 8*M*K output bytes (written once) + ~1 KB of path records per user.
 #include "k2_mfma_frag.h"
+#include "dmx_tuning.h"
 #include <stdlib.h>
 
 namespace dmx {
@@ -81,7 +82,7 @@ __device__ __forceinline__ void mfma_tile(int pt, const unsigned char* Ahi, cons
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], Blo[s], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], Bhi[s], acc, 0, 0, 0);
     }
-    DMX_MFMA_RESULT_GUARD();
+    DMX_MFMA_RESULT_GUARD(acc);
     if (bl.kok) {
         const unsigned tile_off = (unsigned)(pt << 5) * row_bytes;
 #pragma unroll
@@ -116,7 +117,7 @@ __device__ __forceinline__ void mfma_tile_rt(int pt, const unsigned char* Ahi, c
             }
         }
     }
-    DMX_MFMA_RESULT_GUARD();
+    DMX_MFMA_RESULT_GUARD(acc);
     if (bl.kok) {
         const unsigned tile_off = (unsigned)(pt << 5) * row_bytes;
 #pragma unroll
@@ -143,7 +144,7 @@ __device__ __forceinline__ void store_rows(const f16v& acc, float oscale, const 
 
 // chain of tile `pt` into a fresh accumulator while `prev` (tile pt - 1) is stored, a few rows after every K-step
 template <bool NT, int NS, bool STORE_PREV, bool LW>
-__device__ __forceinline__ f16v chain_tile(int pt, const f16v& prev, const unsigned char* Ahi, const unsigned char* Alo, int col, int hh,
+__device__ __forceinline__ f16v chain_tile(int pt, f16v& prev, const unsigned char* Ahi, const unsigned char* Alo, int col, int hh,
                                            const h8 (&Bhi)[4], const h8 (&Blo)[4], const BLane& bl,
                                            __amdgpu_buffer_rsrc_t orsrc, unsigned row_bytes, float oscale) {
     const size_t abase = (size_t)((pt << 5) + col) * ROW_BYTES + (size_t)hh * 16;
@@ -184,6 +185,9 @@ __device__ __forceinline__ f16v chain_tile(int pt, const f16v& prev, const unsig
             __builtin_amdgcn_sched_barrier(0);       // keep this K-step's stores behind its MFMAs and in front of the next reads
         }
     }
+    // right behind the chain, whoever reads the accumulator next (the next tile's threaded stores, the strip's last
+    // stores, or a register copy where two paths of strip_tiles meet)
+    DMX_MFMA_RESULT_GUARD(acc);
     return acc;
 }
 
@@ -200,15 +204,13 @@ __device__ __forceinline__ void strip_tiles(int ntiles, const unsigned char* Ahi
     a0 = chain_tile<NT, NS, false, LW>(0, a0, Ahi, Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale);
     int pt = 1;
     for (; pt + 1 < ntiles; pt += 2) {                                   // a0 holds tile pt - 1
-        const f16v a1 = chain_tile<NT, NS, true, LW>(pt, a0, Ahi, Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale);
+        f16v a1 = chain_tile<NT, NS, true, LW>(pt, a0, Ahi, Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale);
         a0 = chain_tile<NT, NS, true, LW>(pt + 1, a1, Ahi, Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale);
     }
     if (pt < ntiles) {
-        const f16v a1 = chain_tile<NT, NS, true, LW>(pt, a0, Ahi, Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale);
-        DMX_MFMA_RESULT_GUARD();                 // the strip's last tile is stored right behind its chain
-        store_rows<NT, 0, 16>(a1, oscale, bl, orsrc, (unsigned)(pt << 5) * row_bytes, row_bytes);
+        f16v a1 = chain_tile<NT, NS, true, LW>(pt, a0, Ahi, Alo, col, hh, Bhi, Blo, bl, orsrc, row_bytes, oscale);
+        store_rows<NT, 0, 16>(a1, oscale, bl, orsrc, (unsigned)(pt << 5) * row_bytes, row_bytes);   // stored right behind its chain
     } else {
-        DMX_MFMA_RESULT_GUARD();
         store_rows<NT, 0, 16>(a0, oscale, bl, orsrc, (unsigned)((ntiles - 1) << 5) * row_bytes, row_bytes);
     }
 }
@@ -504,7 +506,7 @@ __global__ __launch_bounds__(256) void k2b_beam_project(WsView ws, BeamArgs a) {
 // pairs share the sin/cos work as in gen_b_fragments) and issues 3 MFMAs per 32-beam tile and K-step:
 // 96 MFMAs + ~130 sin/cos pairs per user at 64 beams x 64 elements, instead of 1e5 scalar complex MACs.
 template <int NBT>
-__global__ __launch_bounds__(256) void k2b_beam_project_mfma(WsView ws, BeamArgs a, int64_t user_count, int kkpad, int fstride) {
+__global__ __launch_bounds__(256, 2) void k2b_beam_project_mfma(WsView ws, BeamArgs a, int64_t user_count, int kkpad, int fstride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Fhi = smem;                                              // [NBT*32][fstride]
     unsigned char* Flo = smem + (size_t)NBT * 32 * fstride;
@@ -595,7 +597,7 @@ __global__ __launch_bounds__(256) void k2b_beam_project_mfma(WsView ws, BeamArgs
                     acc[bt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bh, acc[bt], 0, 0, 0);
                 }
             }
-            DMX_MFMA_RESULT_GUARD();
+            DMX_MFMA_RESULT_GUARD_FENCED();
 #pragma unroll
             for (int bt = 0; bt < NBT; ++bt)
 #pragma unroll
@@ -744,7 +746,7 @@ static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user
                            const float2* gtab, hipStream_t stream, const uint2* gpack) {
     MfmaArgs a;
     a.n_beams = n_beams; a.ftab = ftab; a.fexp = fexp; a.gtab = gtab; a.gpack = gpack;
-    a.adaptive = !n_beams && !gtab && !gpack && !getenv("DMX_NO_ADAPTIVE");   // env = measurement hook: always three terms
+    a.adaptive = !n_beams && !gtab && !gpack && (prm.flags & DMX_FLAG_ADAPTIVE_TERMS);   // default: three product terms everywhere
     a.user_begin = user_begin;
     a.m_rx = prm.ue_shape[0] * prm.ue_shape[1];
     a.m_tx = prm.bs_shape[0] * prm.bs_shape[1];
@@ -789,10 +791,10 @@ static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user
         if (gpack) {
             // with the fragments coming out of loads the register-lean tile loop wins at every row count: headline shape
             // x 20k users, stage 2 in all: MODE 0 5.43 ms, MODE 1 5.85, MODE 2 (pipelined, 116 B/lane of scratch) 5.61
-            const char* m1 = getenv("DMX_LPF_TILE_MODE");             // measurement hook: 1 / 2 = the grouped / pipelined bodies
+            const int m1 = tuning_int("DMX_LPF_TILE_MODE", 0);        // tuning build only: 1 / 2 = the grouped / pipelined bodies
             if (small) return launch_mfma_t<true, 4, 0, 2>(ws, a, blocks, smem, out, stream, true, 0);
-            if (a.rows >= 128 && m1 && m1[0] == '1') return launch_mfma_t<true, 8, 1, 2>(ws, a, blocks, smem, out, stream, true, ITEMS_PER_WG8);
-            if (a.rows >= 128 && m1 && m1[0] == '2') return launch_mfma_t<true, 8, 2, 2>(ws, a, blocks, smem, out, stream, true, ITEMS_PER_WG8);
+            if (a.rows >= 128 && m1 == 1) return launch_mfma_t<true, 8, 1, 2>(ws, a, blocks, smem, out, stream, true, ITEMS_PER_WG8);
+            if (a.rows >= 128 && m1 == 2) return launch_mfma_t<true, 8, 2, 2>(ws, a, blocks, smem, out, stream, true, ITEMS_PER_WG8);
             return launch_mfma_t<true, 8, 0, 2>(ws, a, blocks, smem, out, stream, true, ITEMS_PER_WG8);
         }
         if (small) return launch_mfma_t<true, 4, 0, 1>(ws, a, blocks, smem, out, stream, true, 0);

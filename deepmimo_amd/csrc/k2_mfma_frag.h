@@ -15,12 +15,19 @@ static constexpr int MFMA_LDS_MAX = 80 * 1024;   // two workgroups per CU
 static constexpr int LPAD = 32;              // path slots (kk = 64)
 static constexpr float A_SCALE = 64.0f;      // 2^6
 
-// Four wait states the compiler does not know about, placed between the last MFMA of a chain and the first vector read
-// of its accumulator.  The hazard recognizer already puts its 12 there, and 12 is what a direct probe needs
-// (tools/mfma_raw_probe.hip) - yet the folded kernel, which has nothing but those 12, returned accumulator registers 8..15
-// of one tile short of an MFMA's contribution once per 100-400 million user-launches (worse arrangements: once per 200
-// users), and with these four more it did not in 1.75 billion.  Cost: 4 of ~1,000 cycles per tile.
-#define DMX_MFMA_RESULT_GUARD() asm volatile("s_nop 3")
+// Wait states the compiler does not know about, right behind the last MFMA of a chain, on top of the 12 the hazard
+// recognizer puts in front of the first vector read of its accumulator (it counts this statement as ONE of its 12, so
+// `s_nop 4` = five leaves 16 in all) (12 is also what a direct probe needs for the registers
+// written in the last pass: profiles/r2_mfma_hazard_probes.txt item 3, i.e. the recognizer's figure has no margin).
+// The accumulator IS AN OPERAND of the statement ("+v"): every read of it is data-dependent on the asm and cannot be
+// scheduled in front of it.  (Round 2 had `asm volatile("s_nop 3")` without operands; the compiler moved 15 of 16
+// accumulator reads across it - VERDICT r2.)  tests/test_isa_lint.py measures the result in the built code object:
+// >= 16 wait states in front of the first read of any MFMA result in every kernel of this library.
+#define DMX_MFMA_RESULT_GUARD(acc) asm volatile("s_nop 4" : "+v"(acc))
+#define DMX_MFMA_RESULT_GUARD2(acc_a, acc_b) asm volatile("s_nop 4" : "+v"(acc_a), "+v"(acc_b))
+// The same for accumulators the register allocator may keep in AGPRs (a "+v" operand would make it copy them out IN
+// FRONT of the statement): no operands, fenced on both sides against the schedulers instead.
+#define DMX_MFMA_RESULT_GUARD_FENCED() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 4"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
 // (x0, x1) -> packed hi pair and packed lo pair, x = hi + lo.  v_cvt_pkrtz_f16_f32 converts two floats per
 // instruction; with round-toward-zero x - hi is exact in fp32 and lo keeps 11 more bits of it.  The residual is ONE

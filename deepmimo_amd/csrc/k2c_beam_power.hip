@@ -20,6 +20,7 @@
 // K-step of one wide strip of chunk c + 1, then runs its tile against chunk c - one barrier per chunk; with fewer than
 // eight row tiles the waves split the chunk's wide strips among themselves.
 #include "k2_mfma_frag.h"
+#include "dmx_tuning.h"
 #include <stdlib.h>
 
 namespace dmx {
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k2c_beam_power(WsView ws, BeamPowA
                             }
                         }
                         // |Y| of this lane's subcarrier for the 16 rows it holds: both parts are in this lane
-                        DMX_MFMA_RESULT_GUARD();
+                        DMX_MFMA_RESULT_GUARD2(are, aim);
                         // (vector instructions add to the matrix-core time on this chip, square roots do not:
                         // profiles/r2_mfma_valu_overlap.txt - hence packed mul / fma / add around two v_sqrt_f32)
 #pragma unroll
@@ -283,9 +284,8 @@ int launch_beam_power(const dmx_params& prm, const WsView& ws, int64_t user_begi
     a.fexp = t.fexp;
     a.out = out_amp;
     a.best = out_best;
-    a.adaptive = getenv("DMX_NO_ADAPTIVE") == nullptr;              // env = measurement hook: always three terms
-    int nw = 8;
-    if (const char* env = getenv("DMX_BEAM_WAVES")) nw = atoi(env) == 4 ? 4 : 8;      // measurement hook
+    a.adaptive = (prm.flags & DMX_FLAG_ADAPTIVE_TERMS) ? 1 : 0;     // default: three product terms everywhere
+    const int nw = tuning_int("DMX_BEAM_WAVES", 8) == 4 ? 4 : 8;    // tuning build only
     const size_t smem = beam_pow_lds_bytes(a.M, nw);
     if (smem > 160 * 1024) { set_error("%d x %d (rx, beam) rows are too many for the beam-power kernel", a.m_rx, n_beams); return DMX_ERR_SHAPE; }
     const void* kfn = nw == 4 ? reinterpret_cast<const void*>(k2c_beam_power<4>) : reinterpret_cast<const void*>(k2c_beam_power<8>);

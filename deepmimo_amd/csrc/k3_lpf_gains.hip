@@ -12,6 +12,7 @@
 // the direct kernel k3_lpf_gains: one workgroup per (user, kept path), taps and the N roots of unity in
 // LDS, thread k walks d with an exact integer phase index (d*sc_k mod N).
 #include "k2_mfma_frag.h"
+#include "dmx_tuning.h"
 #include <stdlib.h>
 
 namespace dmx {
@@ -350,9 +351,7 @@ int launch_channels_fd_lpf(const dmx_params& prm, const WsView& ws, int64_t user
     // 20k users at the headline shape, before the contraction touched its next strip's table lines ahead of time: one
     // launch 6.31 ms, chunks of 512 7.60, 1024 6.75, 2048 6.09, 4096 6.62; with the touch 5.88 in one launch, 6.06 in
     // chunks of 2048 - so one launch is the default and the chunking stays a measurement hook
-    int64_t chunk = 0;
-    const char* env = getenv("DMX_LPF_CHUNK");                       // measurement hook: users per chunk, 0 = one launch
-    if (env) chunk = atoll(env);
+    const int64_t chunk = tuning_int("DMX_LPF_CHUNK", 0);            // tuning build only: users per chunk, 0 = one launch
     if (chunk <= 0 || chunk >= user_count) return launch_channels_fd_lpf_once(prm, ws, user_begin, user_count, gtab, out, stream);
     const size_t per_user = (size_t)prm.ue_shape[0] * prm.ue_shape[1] * prm.bs_shape[0] * prm.bs_shape[1] * (size_t)prm.n_selected;
     for (int64_t b = 0; b < user_count; b += chunk) {
@@ -375,10 +374,10 @@ static int launch_channels_fd_lpf_once(const dmx_params& prm, const WsView& ws, 
         const bool pow2 = a.N >= 2 && (a.N & (a.N - 1)) == 0;
         int log2n = 0;
         while ((1 << log2n) < a.N) ++log2n;
-        const char* old = getenv("DMX_LPF_OLD_FFT");                  // measurement hook: the workgroup-per-user FFT
-        if (pow2 && a.N >= 64 && a.N <= 2048 && !(old && old[0] == '1')) {
-            const char* nopack = getenv("DMX_LPF_FLOAT_TABLE");        // measurement hook: keep the float table
-            a.pack = packed = lpf_table_packed(prm, ws) && !(nopack && nopack[0] == '1');
+        const bool old = tuning_int("DMX_LPF_OLD_FFT", 0) == 1;       // tuning build only: the workgroup-per-user FFT
+        if (pow2 && a.N >= 64 && a.N <= 2048 && !old) {
+            // tuning build only: DMX_LPF_FLOAT_TABLE=1 keeps the float table
+            a.pack = packed = lpf_table_packed(prm, ws) && tuning_int("DMX_LPF_FLOAT_TABLE", 0) != 1;
             // wave-per-path radix-8 FFT; persistent workgroups (the twiddle table is built once per workgroup)
             const size_t smem = lpf_wave_lds_bytes(a.N);
             const void* kfn = reinterpret_cast<const void*>(k3_lpf_fft_wave);

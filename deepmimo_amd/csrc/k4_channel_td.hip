@@ -8,6 +8,7 @@
 // per table entry instead of one per output element) and multiplies them out; k4_td is the table-free form
 // for panels whose tables exceed LDS.
 #include "dmx_common.h"
+#include "dmx_tuning.h"
 #include <stdlib.h>
 
 namespace dmx {
@@ -117,7 +118,7 @@ int launch_channels_td(const dmx_params& prm, const WsView& ws, int64_t user_beg
     a.ue_mh = prm.ue_shape[0];
     a.bs_mh = prm.bs_shape[0];
     const size_t smem = (size_t)(a.m_rx + a.m_tx) * ws.P * 8;
-    const bool pairs = ((size_t)a.m_rx * a.m_tx * ws.P) % 2 == 0 && ((uintptr_t)out % 16) == 0 && getenv("DMX_TD_NARROW") == nullptr;   // env = measurement hook: 8-byte stores
+    const bool pairs = ((size_t)a.m_rx * a.m_tx * ws.P) % 2 == 0 && ((uintptr_t)out % 16) == 0 && !tuning_set("DMX_TD_NARROW");   // tuning build only: 8-byte stores
     if (smem <= 64 * 1024 && pairs)
         hipLaunchKernelGGL(k4_td_tab<true>, dim3((unsigned)user_count), dim3(256), smem, stream, ws, a, out);
     else if (smem <= 64 * 1024)

@@ -202,7 +202,8 @@ class Dataset(DotDict):
         params = self._params_for_prep()
         rays = eng.upload_rays(self)
         kw = dict(bs_fov=self._data.get("bs_fov"), ue_fov=self._data.get("ue_fov"),
-                  ue_rotation_per_user=self._resolved_ue_rotation(), carrier_freq=self._carrier_freq())
+                  ue_rotation_per_user=self._resolved_ue_rotation(), carrier_freq=self._carrier_freq(),
+                  adaptive_terms=bool(config.get("adaptive_precision", False)))
         prep = eng.prepare(rays, params, want_side=want_side, **kw)
         if want_side:
             self._store_side(prep, None if want_side is True else (rays, params.deepcopy(), kw))

@@ -160,9 +160,11 @@ class ChannelEngine:
 
     # ------------------------------------------------------------------ stage 1
     def prepare(self, rays: DeviceRays, params, bs_fov=None, ue_fov=None, ue_rotation_per_user=None,
-                carrier_freq: float = 0.0, want_side=True) -> PrepResult:
+                carrier_freq: float = 0.0, want_side=True, adaptive_terms: bool = False) -> PrepResult:
         """Run dmx_path_prep.  ue_rotation_per_user: optional [N, 3] degrees (numpy/torch).  want_side: True = every
-        side product, "light" = LoS / path counts / FoV mask only, False = none."""
+        side product, "light" = LoS / path counts / FoV mask only, False = none.  adaptive_terms: opt into
+        DMX_FLAG_ADAPTIVE_TERMS (include/deepmimo_amd.h: weak last path groups in one product term); the flag travels in
+        the parameter block of the preparation, so every stage-2 call on it runs in the same mode."""
         dev = self.device
         n, L = rays.n_ue, rays.n_paths
         ofdm = params[c.PARAMSET_OFDM]
@@ -181,6 +183,7 @@ class ChannelEngine:
         have_dop = rays.doppler_vel is not None and rays.doppler_acc is not None
         p = self._params_struct(params, bs_fov, ue_fov, rot_dev, sel_dev, carrier_freq, have_dop,
                                 sc_hint=uniform_stride(sel))
+        p.flags = nat.FLAG_ADAPTIVE_TERMS if adaptive_terms else 0
 
         r = nat.DmxRays()
         r.n_ue, r.n_paths, r.ld = n, L, L

@@ -44,7 +44,8 @@ class Params(C.Structure):
                 ("selected_subcarriers", C.POINTER(C.c_int32)),
                 ("bandwidth", C.c_double), ("rx_filter", C.c_int32), ("enable_doppler", C.c_int32),
                 ("carrier_freq", C.c_double),
-                ("sc_first", C.c_int32), ("sc_stride", C.c_int32)]     # ABI 2 hint; the twins read the array itself
+                ("sc_first", C.c_int32), ("sc_stride", C.c_int32),     # ABI 2 hint; the twins read the array itself
+                ("flags", C.c_uint32), ("reserved0", C.c_uint32)]      # ABI 3 arithmetic mode; the twins sum in complex128
 
 
 class Side(C.Structure):

@@ -36,7 +36,7 @@ def test_bench_workload_line(workload, users, kernel, bound):
         assert "Doppler" in d["config"]["workload"]
     # the adaptive-precision rule's share is on the line for the kernels that have it, and only for them
     has_rule = kernel in ("k2_fd_mfma", "k2_fd_fold", "k2c_beam_power")
-    assert ("kernel_ms_all_three_terms" in rf) == has_rule
+    assert ("kernel_ms_adaptive_terms" in rf) == has_rule
     if has_rule:
-        assert rf["kernel_ms_all_three_terms"] > 0 and rf["frac_all_three_terms"] == pytest.approx(rf["frac"] * rf["kernel_ms"] / rf["kernel_ms_all_three_terms"])
-        assert "adaptive rule" in d["config"]["arithmetic"]
+        assert rf["kernel_ms_adaptive_terms"] > 0 and rf["frac_adaptive_terms"] == pytest.approx(rf["frac"] * rf["kernel_ms"] / rf["kernel_ms_adaptive_terms"])
+        assert "DMX_FLAG_ADAPTIVE_TERMS" in d["config"]["arithmetic"]

@@ -1,0 +1,121 @@
+"""CPU-side lint of the SHIPPED machine code (no GPU): the gfx950 code objects are pulled out of
+deepmimo_amd/lib/libdeepmimo_amd.so, disassembled, and every MFMA of every kernel is followed through the control-flow
+graph (tools/isa_lint.py).  Round 2's `s_nop 3` "guard" had no operands and the compiler moved 15 of 16 accumulator
+reads across it; nobody noticed because nothing looked at the binary.  What is asserted here is what
+deepmimo_amd/csrc/k2_channel_fd_fold.hip and k2_mfma_frag.h promise, so that the next compiler reschedule cannot undo it
+silently (table and reasoning in DESIGN.md section 4)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import isa_lint  # noqa: E402
+
+LIB = os.path.join(ROOT, "deepmimo_amd", "lib", "libdeepmimo_amd.so")
+pytestmark = pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(isa_lint.OBJDUMP)),
+                                reason="needs the built library and llvm-objdump")
+
+RESULT_READ_MIN = 16      # hazard table / probe: 12 for the 8-pass 32x32x16 f16 MFMA on gfx950; the guard adds >= 4
+WINDOW = 60
+
+
+@pytest.fixture(scope="module")
+def reports():
+    reps = isa_lint.analyse(isa_lint.kernels_of_library(LIB), window=WINDOW)
+    named = {isa_lint.short_name(k): r for k, r in reps.items()}
+    assert any(n.startswith("k2_fd_fold") for n in named) and any(n.startswith("k2_fd_mfma") for n in named) and \
+        any(n.startswith("k2c_beam_power") for n in named) and any(n.startswith("k2b_beam_project_mfma") for n in named), sorted(named)
+    return named
+
+
+def test_parser_on_a_known_sequence():
+    """the tool itself: wait-state counting (s_nop n = n + 1), operand classes, the load-return and result-read figures"""
+    text = """
+0000000000001000 <k>:
+	v_mfma_f32_32x32x16_f16 v[0:15], v[16:19], v[20:23], v[0:15]        // 000000001000: D3D50000
+	ds_read_b128 v[16:19], v40 offset:64                       // 000000001008: D9FE0040
+	s_nop 7                                                    // 000000001010: BF800007
+	v_pk_mul_f32 v[20:21], v[30:31], v[32:33]                  // 000000001014: D3B10014
+	s_nop 3                                                    // 00000000101C: BF800003
+	v_add_f32_e32 v50, v9, v51                                 // 000000001020: 02646709
+	v_mul_f32_e32 v52, v1, v51                                 // 000000001024: 0A686701
+	s_endpgm                                                   // 000000001028: BF810000
+"""
+    k = isa_lint.parse_objdump(text)
+    r = isa_lint.analyse(k, window=40)["k"]
+    assert r.n_mfma == 1
+    assert r.ret["A"][0] == 0                       # the ds_read right behind the MFMA lands in its A operand
+    assert r.valu["B"][0] == 9                      # ds_read (1) + s_nop 7 (8) between the MFMA and the v_pk_mul
+    assert r.raw_hi == 14 and r.raw_lo == 15        # v9 (second half) after 1 + 8 + 1 + 4; v1 one instruction later
+
+
+def test_every_mfma_result_is_read_behind_the_guard(reports):
+    """>= 16 wait states between the last MFMA that writes an accumulator and the first vector read of ANY of its
+    registers, in every matrix-core kernel of the library (the recognizer's 12 have no margin: probe item 3)."""
+    bad = {n: (r.raw_lo, r.raw_lo_at, r.raw_hi, r.raw_hi_at) for n, r in reports.items()
+           if min(r.raw_lo, r.raw_hi) < RESULT_READ_MIN}
+    assert not bad, bad
+
+
+def test_no_vector_write_into_a_fresh_accumulator(reports):
+    """write-after-write / write-after-read on vDst / SrcC: the hazard table asks for 12 / 13 wait states"""
+    bad = {n: r.valu["C"] for n, r in reports.items() if "C" in r.valu and r.valu["C"][0] < RESULT_READ_MIN}
+    assert not bad, bad
+
+
+def test_folded_kernel_operands_are_not_shared_with_the_next_loads(reports):
+    """k2_fd_fold: no DS / VMEM load returns into a register that an MFMA issued within the last 12 wait states names as
+    A or B (the table entries have registers of their own), none into its accumulator within 16; the first vector write
+    into an issued MFMA's A / B registers comes >= 8 wait states later; an MFMA group accumulates onto the group two
+    K-steps back (>= 48 wait states), never onto the one just issued."""
+    folds = {n: r for n, r in reports.items() if n.startswith("k2_fd_fold")}
+    assert len(folds) == 2
+    for n, r in folds.items():
+        for op, lim in (("A", 12), ("B", 12), ("C", 16)):
+            assert op not in r.ret or r.ret[op][0] >= lim, (n, op, r.ret[op])
+        for op in ("A", "B"):
+            assert op not in r.valu or r.valu[op][0] >= 8, (n, op, r.valu[op])
+        assert r.dep_max == 0 or r.dep_min >= 48, (n, r.dep_min, r.dep_max, r.dep_hist)
+        assert r.dep_branches == 0, (n, r.dep_branches)
+
+
+def _notes(path):
+    out = subprocess.run([os.path.join(isa_lint.LLVM_BIN, "llvm-readelf"), "--notes", path], capture_output=True, text=True).stdout
+    info, name = {}, None
+    for line in out.split("\n"):
+        t = line.strip()
+        if t.startswith(".name:"):
+            name = t.split()[-1]
+            info[name] = {}
+        for key in (".vgpr_count:", ".vgpr_spill_count:", ".private_segment_fixed_size:"):
+            if t.startswith(key) and name:
+                info[name][key.strip(".:")] = int(t.split()[-1])
+    return info
+
+
+def test_folded_kernel_register_budget_and_residency(tmp_path):
+    """k2_fd_fold names v[108:127] in its asm statements: it must be compiled for exactly the 128 registers of four
+    waves per SIMD, and (all non-reproducible builds of round 2 ran at five) never be resident at more: the launcher pads
+    the LDS request to more than a fifth of a CU's 160 KiB - checked on the source constant and on the VGPR count."""
+    info = {}
+    for co in isa_lint.extract_code_objects(LIB, str(tmp_path)):
+        info.update(_notes(co))
+    folds = {k: v for k, v in info.items() if "k2_fd_fold" in k}
+    assert len(folds) == 2
+    for k, v in folds.items():
+        assert 104 < v["vgpr_count"] <= 128, (k, v)           # 104 or fewer would allow a fifth wave per SIMD
+    src = open(os.path.join(ROOT, "deepmimo_amd", "csrc", "k2_channel_fd_fold.hip")).read()
+    assert "FOLD_MIN_LDS = 160 * 1024 / 5 + 64" in src and "if (smem < FOLD_MIN_LDS) smem = FOLD_MIN_LDS;" in src
+
+
+def test_library_reads_no_environment_variable():
+    """include/deepmimo_amd.h: no global state but the thread-local error string.  The measurement hooks of round 2
+    (getenv at every launch) exist only in the -DDMX_TUNING_HOOKS build (deepmimo_amd/csrc/dmx_tuning.h)."""
+    syms = subprocess.run(["nm", "-D", "--undefined-only", LIB], capture_output=True, text=True).stdout
+    assert "getenv" not in syms, [s for s in syms.split("\n") if "getenv" in s]
+    for f in os.listdir(os.path.join(ROOT, "deepmimo_amd", "csrc")):
+        if f.endswith((".hip", ".cpp")):
+            assert "getenv" not in open(os.path.join(ROOT, "deepmimo_amd", "csrc", f)).read(), f
