@@ -25,6 +25,7 @@ class _Config:
         "fd_kernel_variant": 0,      # 0 auto, 1 fp32 vector kernel, 2 split-precision MFMA kernel, 9 small-output kernel, 12 folded
         "strict_reference_cache": False,   # True: keep the reference's stale `_power_linear_ant_gain` (dataset.py:213-220)
         "host_copy_guard": True,     # refuse a NumPy copy of the channel tensor that exceeds the free host memory
+        "array_response_max_bytes": 2 << 30,   # largest `array_response_product` ([N, M_rx, M_tx, L] complex128) built on request
         "adaptive_precision": False,  # True: DMX_FLAG_ADAPTIVE_TERMS - a user's weak last path group in ONE f16 product term
                                       # (<= 7.6e-6 of the strongest path instead of ~2e-6; 3-5 % faster at 25 paths)
     }

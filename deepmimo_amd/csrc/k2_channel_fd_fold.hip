@@ -524,13 +524,32 @@ __global__ __launch_bounds__(256, 4) void k2_fd_fold(WsView ws, FoldArgs a, floa
         float* __restrict__ o = out + (size_t)ul * user_floats + (size_t)a0 * 32;
         fold_sync<WS>();                                                   // the previous chunk's tiles have read E1
         // E1[a][l] = e^{-j 2pi q_l sc(16 (a0 + a))}; q = qh + ql with qh a multiple of 2^-12, so qh * (sc mod 4096) is
-        // exact in float32 and qh * (sc - sc mod 4096) is an integer (k2_channel_fd_mfma.hip gen_b_step)
-        for (int ab = 2 * sub + hh; ab < nb; ab += 2 * WS) {
-            const int sca = a.sc_first + a.sc_stride * 16 * (a0 + ab);
-            const float p1 = qhf * (float)(sca & 4095);
-            float s, c;
-            sincos_rev(fmaf(qlf, (float)sca, p1 - rintf(p1)), s, c);
-            *reinterpret_cast<float2*>(E1 + (size_t)ab * FOLD_TROW + lp * 8) = make_float2(c, -s);
+        // exact in float32 and qh * (sc - sc mod 4096) is an integer (k2_channel_fd_mfma.hip gen_b_step).  A lane walks the
+        // blocks ab, ab + 2 WS, ...: every eighth entry is evaluated like that, the seven behind it by ONE complex
+        // multiplication with the step phasor W = e^{-j 2pi q_l 32 WS d} (4 instead of ~12 vector instructions per entry;
+        // <= 7 float32 roundings of ~6e-8 on top of the hardware sin / cos's 1.25e-7).
+        {
+            const int dsc = a.sc_stride * 32 * WS;
+            const float pw = qhf * (float)(dsc & 4095);
+            float ws_, wc_;
+            sincos_rev(fmaf(qlf, (float)dsc, pw - rintf(pw)), ws_, wc_);
+            const float wr = wc_, wi = -ws_;
+            float er_ = 1.f, ei_ = 0.f;
+            int it = 0;
+            for (int ab = 2 * sub + hh; ab < nb; ab += 2 * WS, ++it) {
+                if ((it & 7) == 0) {                                       // wave-uniform
+                    const int sca = a.sc_first + a.sc_stride * 16 * (a0 + ab);
+                    const float p1 = qhf * (float)(sca & 4095);
+                    float s, c;
+                    sincos_rev(fmaf(qlf, (float)sca, p1 - rintf(p1)), s, c);
+                    er_ = c; ei_ = -s;
+                } else {
+                    const float t = fmaf(-ei_, wi, er_ * wr);
+                    ei_ = fmaf(ei_, wr, er_ * wi);
+                    er_ = t;
+                }
+                *reinterpret_cast<float2*>(E1 + (size_t)ab * FOLD_TROW + lp * 8) = make_float2(er_, ei_);
+            }
         }
         fold_sync<WS>();
 

@@ -416,6 +416,41 @@ class Dataset(DotDict):
     def _compute_power_linear_ant_gain(self) -> np.ndarray:
         return self._side(c.PWR_LINEAR_ANT_GAIN_PARAM_NAME)
 
+    def _compute_array_response_product(self) -> np.ndarray:
+        """complex128 [n_ue, M_rx, M_tx, L] product of the two array responses (dataset.py:398-417), from the rotated,
+        FoV-filtered angles stage 1 produced on the GPU.  The channel kernels never form this tensor (10 GB at the
+        headline shape, 82 GB at config 5 - they generate it per tile); it exists for callers that read the public
+        attribute, on the host and for sizes that fit: above `config('array_response_max_bytes')` (default 2 GiB) a
+        MemoryError names the alternatives instead of the bare KeyError an unknown attribute would raise."""
+        from .geometry import _ant_indices
+        p = self.ch_params
+        bs, ue = p[c.PARAMSET_ANT_BS], p[c.PARAMSET_ANT_UE]
+        m_tx, m_rx = int(np.prod(bs[c.PARAMSET_ANT_SHAPE])), int(np.prod(ue[c.PARAMSET_ANT_SHAPE]))
+        n, L = self[c.POWER_PARAM_NAME].shape
+        need = 16 * n * m_rx * m_tx * L
+        limit = int(config.get("array_response_max_bytes", 2 << 30))
+        if need > limit:
+            raise MemoryError(
+                f"array_response_product would take {need / 1e9:.1f} GB ([{n}, {m_rx}, {m_tx}, {L}] complex128); the GPU path never "
+                f"materialises it - use compute_channels() / dataset.channel (or compute_beam_power), read it for a "
+                f"dataset.subset(idxs) of users, or raise config('array_response_max_bytes')")
+        aod_el, aod_az = self[c.AOD_EL_FOV_PARAM_NAME], self[c.AOD_AZ_FOV_PARAM_NAME]
+        aoa_el, aoa_az = self[c.AOA_EL_FOV_PARAM_NAME], self[c.AOA_AZ_FOV_PARAM_NAME]
+
+        def resp(ant, theta, phi):                                           # geometry.py:38-102
+            idx = _ant_indices(ant[c.PARAMSET_ANT_SHAPE]).astype(np.float64)
+            kd = 2 * np.pi * float(ant[c.PARAMSET_ANT_SPACING])
+            out = np.zeros((theta.shape[0], idx.shape[0], theta.shape[1]), dtype=np.complex128)
+            ok = ~np.isnan(theta)
+            t, f = theta[ok], phi[ok]
+            gamma = 1j * kd * np.stack([np.sin(t) * np.cos(f), np.sin(t) * np.sin(f), np.cos(t)], axis=0)   # [3, n_valid]
+            ub, ul = np.nonzero(ok)
+            out[ub, :, ul] = np.exp(idx @ gamma).T
+            return out
+
+        a_tx, a_rx = resp(bs, aod_el, aod_az), resp(ue, aoa_el, aoa_az)
+        return a_rx[:, :, None, :] * a_tx[:, None, :, :]
+
     def _compute_n_ue(self) -> int:
         return self.rx_pos.shape[0]                                          # dataset.py:657-659
 
@@ -554,6 +589,7 @@ class Dataset(DotDict):
         "grid_spacing": "_compute_grid_info",
         c.INTER_STR_PARAM_NAME: "_compute_inter_str",
         c.INTER_INT_PARAM_NAME: "_compute_inter_int",
+        "array_response_product": "_compute_array_response_product",       # dataset.py:849
     }
 
 

@@ -122,11 +122,15 @@ def macro_shard_plan(n_users: List[int], world: int, rank: int) -> List[Tuple[in
     return plan
 
 
-def gather_macro_to_root(pieces: Dict[int, torch.Tensor], n_users: List[int], dst: int = 0, group=None) -> Optional[List[torch.Tensor]]:
+def gather_macro_to_root(pieces: Dict[int, torch.Tensor], n_users: List[int], dst: int = 0, group=None,
+                         trailing_shape=None, dtype=None, device=None) -> Optional[List[torch.Tensor]]:
     """Bring a MacroDataset's sharded results together on rank `dst`: ``pieces[i]`` is this rank's block of
     basestation i (as planned by ``macro_shard_plan``; absent when the rank holds none of it).  Returns the list of
     full per-basestation tensors on `dst` (what MacroDataset.compute_channels returns in one process), None elsewhere.
-    Point-to-point fan-in, one batch per rank, as in ``gather_users_to_root``."""
+    Point-to-point fan-in, one batch per rank, as in ``gather_users_to_root``.  The receive buffers take their trailing
+    shape / dtype / device from `trailing_shape`, `dtype`, `device` when given, else from a piece `dst` holds itself;
+    when `dst` holds none (fewer users than ranks) and they are not given, EVERY rank raises - the other ranks would
+    otherwise wait for a receive that is never posted."""
     rank, world = _world(group)
     plans = [macro_shard_plan(n_users, world, r) for r in range(world)]
     mine = {i: (b, e) for i, b, e in plans[rank]}
@@ -136,11 +140,17 @@ def gather_macro_to_root(pieces: Dict[int, torch.Tensor], n_users: List[int], ds
     if world == 1:
         return [pieces[i] for i in range(len(n_users))]
     dist = _dist()
-    # trailing shape / dtype come from any piece this rank holds; every rank holds at least one unless it has no users
+    if (trailing_shape is None or dtype is None) and not plans[dst]:
+        # the same condition on every rank (the plan is a pure function of n_users and the world size): nobody posts anything
+        raise ValueError(f"gather_macro_to_root: rank {dst} holds no user block (users per basestation {list(n_users)}, "
+                         f"{world} ranks), so the receive buffers' trailing shape and dtype must be passed explicitly")
     ops, outs = [], None
     if rank == dst:
-        ref = next(iter(pieces.values()))
-        outs = [torch.empty((n,) + tuple(ref.shape[1:]), dtype=ref.dtype, device=ref.device) for n in n_users]
+        ref = next(iter(pieces.values())) if pieces else None
+        tshape = tuple(trailing_shape) if trailing_shape is not None else tuple(ref.shape[1:])
+        dt = dtype if dtype is not None else ref.dtype
+        dev = device if device is not None else (ref.device if ref is not None else torch.device("cpu"))
+        outs = [torch.empty((n,) + tshape, dtype=dt, device=dev) for n in n_users]
         for r in range(world):
             for i, b, e in plans[r]:
                 if r == dst:

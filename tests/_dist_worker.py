@@ -47,6 +47,20 @@ def main():
             assert torch.equal(full[i].real[:, 1, 2, 3], torch.arange(n, dtype=torch.float32) + 1000 * i)
     else:
         assert full is None
+    # fewer users than ranks: the root may hold no block at all.  With the trailing shape given the gather still works;
+    # without it EVERY rank raises (none would post its half of the exchange) instead of the others hanging
+    if world >= 2:
+        tiny = [1]
+        root = world - 1                                            # the single user lands on rank 0
+        pieces = {i: torch.full((ue - ub, 2), 7.0) for i, ub, ue in ddist.macro_shard_plan(tiny, world, rank)}
+        full = ddist.gather_macro_to_root(pieces, tiny, dst=root, trailing_shape=(2,), dtype=torch.float32)
+        if rank == root:
+            assert len(full) == 1 and torch.equal(full[0], torch.full((1, 2), 7.0))
+        try:
+            ddist.gather_macro_to_root(pieces, tiny, dst=root)
+            raise AssertionError("expected ValueError on every rank")
+        except ValueError as exc:
+            assert "holds no user block" in str(exc)
     # max-over-ranks timing reduction used by bench.py
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
