@@ -53,6 +53,10 @@ WORKLOADS = {
     "c3_time_domain": dict(n_ue=100_000, bs=[8, 8], ue=[2, 2], L=25, N=512, td=True),
     "c3_rx_filter": dict(n_ue=100_000, bs=[8, 8], ue=[2, 2], L=25, N=512, lpf=True),
     "tiny": dict(n_ue=512, bs=[8, 8], ue=[2, 2], L=25, N=512),
+    # the step BEFORE the path (core.py:186-258): a converted scenario folder of asu_campus size
+    # (411 x 321 = 131,931 receivers, test/test_v3_correspondence.py:49) -> device SoA -> compute_channels with
+    # DeepMIMO's default arrays.  A different kind of bench line: see bench_loader().
+    "load_asu_shape": dict(n_ue=131_931, bs=[8, 1], ue=[1, 1], L=25, N=512, loader=True),
 }
 
 
@@ -90,6 +94,133 @@ def make_params(w):
     p.ofdm.rx_filter = int(bool(w.get("lpf")))
     p.validate(w["n_ue"])
     return p
+
+
+def bench_loader(args, w, dev):
+    """`--workload load_asu_shape`: scenario folder -> `dm.load(..., device='cuda')` -> `compute_channels`, timed end to
+    end and in parts, against the reference's loading model (`scipy.io.loadmat` per matrix, core.py:241, then an upload)
+    on the same files.  A "step" is one whole load + generate of the scenario; `value` stays user-channels/s (users of
+    the scenario / step time) and `roofline` is the device transpose kernel's (`k_mat_to_rowmajor`: bytes of the stored
+    payload read + bytes of the row-major matrix written, per field)."""
+    import shutil
+    import tempfile
+    import scipy.io
+    import deepmimo_amd as dm
+    from deepmimo_amd import matio
+    n, L = w["n_ue"] if not args.users else args.users, w["L"]
+    root = tempfile.mkdtemp(prefix="dmx_scen_", dir=os.environ.get("TMPDIR", "/tmp"))
+    folder = os.path.join(root, "asu_shape")
+    os.makedirs(folder)
+    try:
+        rng = np.random.default_rng(7)
+        nvalid = rng.integers(0, L + 1, size=(n, 1))
+        pad = np.arange(L)[None, :] >= nvalid
+
+        def U(lo, hi):
+            m = rng.uniform(lo, hi, size=(n, L)).astype(np.float32)
+            m[pad] = np.nan
+            return m
+
+        mats = {"power": U(-140, -60), "phase": U(-180, 180), "delay": U(1e-8, 2e-6), "aoa_az": U(-180, 180),
+                "aoa_el": U(0, 180), "aod_az": U(-180, 180), "aod_el": U(0, 180)}
+        inter = rng.integers(0, 5, size=(n, L)).astype(np.float32)
+        inter[pad] = np.nan
+        mats["inter"] = inter
+        mats["rx_pos"] = rng.uniform(0, 400, size=(n, 3)).astype(np.float32)
+        mats["tx_pos"] = np.array([[200.0, 160.0, 25.0]], dtype=np.float32)
+        params = {"rt_params": {"frequency": 3.5e9}, "scene": {"num_scenes": 1}, "materials": {},
+                  "txrx_sets": {"txrx_set_0": {"id": 0, "is_tx": True, "is_rx": False, "num_points": 1, "name": "bs"},
+                                "txrx_set_1": {"id": 1, "is_tx": False, "is_rx": True, "num_points": n, "name": "ue"}}}
+        with open(os.path.join(folder, "params.json"), "w") as f:
+            json.dump(params, f)
+        file_bytes = 0
+        for k, v in mats.items():
+            path = os.path.join(folder, dm.core.get_mat_filename(k, 0, 0, 1))
+            scipy.io.savemat(path, {k: v})                       # what the converter writes (converter_utils.py:59-85)
+            file_bytes += os.path.getsize(path)
+        ray_bytes = 8 * n * L * 4
+        chp = make_params(dict(w, n_ue=n))
+        dm.config("channel_output", "torch")
+
+        def one_step():
+            t0 = time.perf_counter()
+            ds = dm.load(folder, device="cuda")
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            H = ds.compute_channels(chp)
+            torch.cuda.synchronize(dev)
+            t2 = time.perf_counter()
+            assert tuple(H.shape) == (n, 1, w["bs"][0] * w["bs"][1], w["N"]) and bool(torch.isfinite(torch.view_as_real(H[:: max(1, n // 64)])).all())
+            los = ds.los
+            return t1 - t0, t2 - t1, ds, los
+
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):          # the loader prints one line per TX/RX pair, as the reference does
+            for _ in range(max(1, args.warmup)):
+                one_step()
+            loads, gens = [], []
+            for _ in range(max(1, args.steps)):
+                a, b, ds, _ = one_step()
+                loads.append(a)
+                gens.append(b)
+            # the parts of the device path, one field at a time: file pages -> HBM (as stored), then the layout kernel
+            path = os.path.join(folder, dm.core.get_mat_filename("power", 0, 0, 1))
+            evs = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                payload = torch.empty(n * L, dtype=torch.float32, device=dev).uniform_(-1, 1)
+                out = torch.empty((n, L), dtype=torch.float32, device=dev)
+                import ctypes as C
+                from deepmimo_amd import _native as nat
+                e0.record()
+                nat.check(nat.load().dmx_mat_to_rowmajor_f32(C.c_void_p(payload.data_ptr()), 7, n, L, None, n, L,
+                                                             C.c_void_p(out.data_ptr()),
+                                                             C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "dmx_mat_to_rowmajor_f32")
+                e1.record()
+                torch.cuda.synchronize(dev)
+                evs.append(e0.elapsed_time(e1))
+            k_ms = float(np.min(evs))
+            t0 = time.perf_counter()
+            t = matio.load_matrix_to_device(path, "power", dev)
+            torch.cuda.synchronize(dev)
+            one_field_s = time.perf_counter() - t0
+            # the reference's model on the same files: scipy.io.loadmat per matrix + slicing (core.py:241-254), then the upload
+            t0 = time.perf_counter()
+            host = dm.load(folder)
+            t_scipy = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            _ = {k: torch.from_numpy(np.ascontiguousarray(host[k])).to(dev) for k in dm.consts.RAY_FIELDS}
+            torch.cuda.synchronize(dev)
+            t_upload = time.perf_counter() - t0
+        dm.config.reset()
+        load_s, gen_s = float(np.median(loads)), float(np.median(gens))
+        step_s = load_s + gen_s
+        k_bytes = 2 * n * L * 4
+        res = {
+            "metric": "user-channels/sec", "value": n / step_s, "unit": "user-channels/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"load_asu_shape: scenario folder of {n} receivers x {L} paths (8 ray matrices as MAT-v5 files, "
+                                   f"{file_bytes / 1e6:.0f} MB on disk, page cache warm) -> dm.load(device='cuda') -> compute_channels "
+                                   f"(BS {w['bs'][0]}x{w['bs'][1]}, UE 1x1, {w['N']} subcarriers, output kept in HBM); one step = the whole load + generate",
+                       "users_total": n, "parallelism": "user-shard x1", "library_id": library_id()},
+            "roofline": {"bound": "hbm", "achieved": k_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_mat_to_rowmajor (column-major payload -> row-major float32, one ray matrix)", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_launch": k_bytes,
+                         "note": "13 MB per launch: far too small to reach the HBM rate, and 8 such launches are 0.1 % of a load - the loader is bound by the host side (below)"},
+            "loader": {"load_ms": load_s * 1e3, "compute_channels_ms": gen_s * 1e3,
+                       "ray_bytes": ray_bytes, "load_GBps_on_ray_bytes": ray_bytes / load_s / 1e9,
+                       "pcie_measured_GBps": 57.0, "load_frac_of_pcie": ray_bytes / load_s / 1e9 / 57.0,
+                       "one_field_file_to_device_ms": one_field_s * 1e3,
+                       "reference_model": {"what": "dm.load(folder) on the host = scipy.io.loadmat per matrix + slicing (core.py:241-254), then torch upload of the 8 ray fields",
+                                           "loadmat_ms": t_scipy * 1e3, "upload_ms": t_upload * 1e3,
+                                           "speedup_of_device_loader": (t_scipy + t_upload) / load_s}},
+        }
+        print(json.dumps(res))
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def _cpu_chunk(args):
@@ -270,6 +401,10 @@ def main():
 
     from deepmimo_amd.engine import ChannelEngine
     w = dict(WORKLOADS[args.workload])
+    if w.get("loader"):
+        if world != 1:
+            raise SystemExit("load_asu_shape is a single-process workload")
+        return bench_loader(args, w, dev)
     if args.users:
         w["n_ue"] = args.users
     n_ue = w["n_ue"]

@@ -105,6 +105,26 @@ __device__ __forceinline__ void rotate_dir(float el_deg, float az_deg, double sx
     im = cy * sx * ct + st * (sy * sx * cd + cx * sd);
 }
 
+// The same for an EXACTLY zero rotation (DeepMIMO's default, channel.py:36-46): with sin = 0 and cos = 1 every product of
+// geometry.py:294-310 that carries a rotation term is an exact zero and the sums are exact, so
+//   zc = cos(zenith),  re = sin(zenith) cos(azimuth),  im = sin(zenith) sin(azimuth)
+// are the very numbers the general expressions give (NaN inputs propagate the same way) - 4 float64 operations instead
+// of 20.  sphi = sin(azimuth') = im / |re + j im| is sign(sin zenith) sin(azimuth) up to the 1e-16 by which the float64
+// sin / cos pair misses the unit circle (the general path divides by that norm): no square root, no division.
+__device__ __forceinline__ void rotate_dir_zero(float el_deg, float az_deg, double& zc, double& re, double& im, double& sphi) {
+    const float th32 = el_deg * D2R_F;
+    const float ph32 = az_deg * D2R_F;
+    float st32, ct32;
+    np_sincosf(th32, st32, ct32);
+    const double st = (double)st32, ct = (double)ct32;
+    double sd, cd;
+    sincos((double)ph32, &sd, &cd);
+    zc = isnan(sd) ? sd : ct;
+    re = st * cd;
+    im = st * sd;
+    sphi = st > 0.0 ? sd : (st < 0.0 ? -sd : 0.0);
+}
+
 // np.mod(x, 2pi): result takes the sign of the divisor
 __device__ __forceinline__ double pymod_2pi(double x) {
     double m = fmod(x, TWO_PI);
@@ -144,7 +164,8 @@ __device__ __forceinline__ uint32_t float_order_key(float f) {
 // LEAN = nothing needs the angles as numbers (no FoV, isotropic patterns, no angle / power side outputs - what
 // compute_channels and bench.py run): the arccos / atan2 / FoV / dipole code is compiled out, which takes the kernel
 // from 228 to far fewer registers, i.e. from 2 to 3-4 waves per SIMD on a kernel that waits on its loads and stores.
-template <int LPU, bool LEAN>
+// ZROT (with LEAN): both rotations are exactly zero and the same for every user.
+template <int LPU, bool LEAN, bool ZROT = false>
 __global__ __launch_bounds__(256, LEAN ? 4 : 2) void k1_path_prep(PrepArgs a) {
     constexpr int UPW = 64 / LPU;                           // users per wave
     const int lane = threadIdx.x & (LPU - 1);               // lane inside the user's group
@@ -188,9 +209,14 @@ __global__ __launch_bounds__(256, LEAN ? 4 : 2) void k1_path_prep(PrepArgs a) {
         const float aod_el = in ? r.aod_el[row + j] : nan32;
         const float inter = in ? r.inter[row + j] : nan32;
 
-        double zc_t, re_t, im_t, zc_r, re_r, im_r;
-        rotate_dir(aod_el, aod_az, a.bsx, a.csx, a.bsy, a.csy, a.brz, zc_t, re_t, im_t);
-        rotate_dir(aoa_el, aoa_az, usx, ucx, usy, ucy, urz, zc_r, re_r, im_r);
+        double zc_t, re_t, im_t, zc_r, re_r, im_r, sphi_t = 0.0, sphi_r = 0.0;
+        if constexpr (ZROT) {
+            rotate_dir_zero(aod_el, aod_az, zc_t, re_t, im_t, sphi_t);
+            rotate_dir_zero(aoa_el, aoa_az, zc_r, re_r, im_r, sphi_r);
+        } else {
+            rotate_dir(aod_el, aod_az, a.bsx, a.csx, a.bsy, a.csy, a.brz, zc_t, re_t, im_t);
+            rotate_dir(aoa_el, aoa_az, usx, ucx, usy, ucy, urz, zc_r, re_r, im_r);
+        }
         // arccos is NaN outside [-1, 1]; np.angle is NaN only for NaN input
         double th_t = (isnan(zc_t) || fabs(zc_t) > 1.0) ? nan64 : 0.0, ph_t = (isnan(re_t) || isnan(im_t)) ? nan64 : 0.0;
         double th_r = (isnan(zc_r) || fabs(zc_r) > 1.0) ? nan64 : 0.0, ph_r = (isnan(re_r) || isnan(im_r)) ? nan64 : 0.0;
@@ -291,7 +317,10 @@ __global__ __launch_bounds__(256, LEAN ? 4 : 2) void k1_path_prep(PrepArgs a) {
             keep = valid;                                                  // slot even if coefficient is 0
         }
         double ty = 0.0, tz = 0.0, ry = 0.0, rz = 0.0;
-        if (ang_ok) {                                        // geometry.py:99-101 in revolutions (kd / 2pi = spacing)
+        if (ang_ok && ZROT) {
+            ty = a.bs_spacing * (sqrt(1.0 - zc_t * zc_t) * sphi_t); tz = a.bs_spacing * zc_t;
+            ry = a.ue_spacing * (sqrt(1.0 - zc_r * zc_r) * sphi_r); rz = a.ue_spacing * zc_r;
+        } else if (ang_ok) {                                 // geometry.py:99-101 in revolutions (kd / 2pi = spacing)
             const double rho_t = sqrt(re_t * re_t + im_t * im_t), rho_r = sqrt(re_r * re_r + im_r * im_r);
             ty = a.bs_spacing * (sqrt(1.0 - zc_t * zc_t) * (rho_t > 0.0 ? im_t / rho_t : 0.0)); tz = a.bs_spacing * zc_t;
             ry = a.ue_spacing * (sqrt(1.0 - zc_r * zc_r) * (rho_r > 0.0 ? im_r / rho_r : 0.0)); rz = a.ue_spacing * zc_r;
@@ -364,9 +393,12 @@ int launch_path_prep(const dmx_rays& rays, const dmx_params& prm, const WsView& 
                     side.aod_el_rot || side.aod_az_rot || side.aoa_el_rot || side.aoa_az_rot;
     if (rays.n_ue == 0) return DMX_OK;
     const bool lean = !a.need_angles && !side.power_linear && !side.power_linear_ant_gain && !side.fov_mask;
+    bool zrot = lean && !prm.ue_rotation_per_user;
+    for (int i = 0; i < 3; ++i) zrot = zrot && prm.bs_rotation[i] == 0.0 && prm.ue_rotation[i] == 0.0;
     if (rays.n_paths <= 32) {
         const unsigned grid = (unsigned)((rays.n_ue + 7) / 8);
-        if (lean) hipLaunchKernelGGL((k1_path_prep<32, true>), dim3(grid), dim3(256), 0, stream, a);
+        if (zrot) hipLaunchKernelGGL((k1_path_prep<32, true, true>), dim3(grid), dim3(256), 0, stream, a);
+        else if (lean) hipLaunchKernelGGL((k1_path_prep<32, true>), dim3(grid), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((k1_path_prep<32, false>), dim3(grid), dim3(256), 0, stream, a);
     } else {
         const unsigned grid = (unsigned)((rays.n_ue + 3) / 4);
