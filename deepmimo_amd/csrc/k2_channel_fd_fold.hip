@@ -437,8 +437,9 @@ __global__ __launch_bounds__(256, 4) void k2_fd_fold(WsView ws, FoldArgs a, floa
     constexpr int IW = 4 / WS;                                             // work items a workgroup has in flight
     const int sub = WS == 4 ? wave : 0;                                    // this wave's share of table rows / row tiles
     for (int64_t item = (int64_t)blockIdx.x * IW + (WS == 1 ? wave : 0); item < items; item += (int64_t)gridDim.x * IW) {
-        const int64_t ul = item / a.nsuper;
-        const int sc = (int)(item - ul * a.nsuper);
+        // one work item per user up to 1024 subcarriers: no 64-bit division (~80 instructions) per item
+        const int64_t ul = a.nsuper == 1 ? item : item / a.nsuper;
+        const int sc = a.nsuper == 1 ? 0 : (int)(item - ul * a.nsuper);
         const int64_t u = a.user_begin + ul;
         const int b0 = sc * a.sch;                                         // first subcarrier block of this item
         const int bn = (a.nblk - b0) < a.sch ? (a.nblk - b0) : a.sch;      // its blocks

@@ -108,87 +108,6 @@ __global__ __launch_bounds__(256) void k4_td_tab(WsView ws, TdArgs a, float2* __
     }
 }
 
-// Persistent form of k4_td_tab (round 3): a workgroup strides over the users with TWO sets of factor tables.  The
-// tables of user u + 1 are built (global loads of its records, range reduction, sin / cos, LDS writes) IN FRONT of the
-// stores of user u in every thread's instruction stream, so the loads never queue behind a burst of stores on the
-// in-order vmcnt, and one barrier per user replaces a workgroup launch + table phase + barrier + drain per user
-// (100k workgroups of 51 KB each at the headline shape: 1.03 ms = 0.62 of HBM).
-template <bool PAIRS>
-__device__ __forceinline__ void td_build_tables(const WsView& ws, const TdArgs& a, int64_t u, float2* tab) {
-    const int P = ws.P;
-    const int n_keep = ws.n_keep[u];
-    const size_t rb = (size_t)u * P;
-    for (int i = threadIdx.x; i < (a.m_rx + a.m_tx) * P; i += 256) {
-        const int e = i / P, s = i - e * P;                 // e < m_rx: receive element, else transmit element
-        float2 v = make_float2(0.f, 0.f);
-        if (s < n_keep) {
-            float sn, cs;
-            if (e < a.m_rx) {
-                sincos_rev(frac_rev((double)(e % a.ue_mh) * ws.rx_y[rb + s] + (double)(e / a.ue_mh) * ws.rx_z[rb + s]), sn, cs);
-                const float cr = ws.c_re[rb + s], ci = ws.c_im[rb + s];
-                v = make_float2(cr * cs - ci * sn, cr * sn + ci * cs);
-            } else {
-                const int t = e - a.m_rx;
-                sincos_rev(frac_rev((double)(t % a.bs_mh) * ws.tx_y[rb + s] + (double)(t / a.bs_mh) * ws.tx_z[rb + s]), sn, cs);
-                v = make_float2(cs, sn);
-            }
-        }
-        tab[i] = v;                                         // b_rx [m_rx][P] then a_tx [m_tx][P], contiguous
-    }
-}
-
-template <bool PAIRS>
-__global__ __launch_bounds__(256) void k4_td_persist(WsView ws, TdArgs a, float2* __restrict__ out, int64_t user_count) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int P = ws.P;
-    const size_t tab_elems = (size_t)(a.m_rx + a.m_tx) * P;
-    float2* tabs[2] = {reinterpret_cast<float2*>(smem), reinterpret_cast<float2*>(smem) + tab_elems};
-    const size_t per_user = (size_t)a.m_rx * a.m_tx * P;
-    constexpr unsigned STEP = PAIRS ? 512u : 256u;
-    const unsigned tid = threadIdx.x;
-    const unsigned e0 = PAIRS ? 2u * tid : tid;
-    const unsigned uP = (unsigned)P, uT = (unsigned)a.m_tx;
-    const unsigned s_first = e0 % uP, q_first = e0 / uP;
-    const unsigned m_first = q_first % uT, r_first = q_first / uT;
-    const unsigned ds = STEP % uP, dq = STEP / uP;
-    const unsigned dm = dq % uT, dr = dq / uT;
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    int64_t ul = blockIdx.x;
-    if (ul >= user_count) return;
-    td_build_tables<PAIRS>(ws, a, a.user_begin + ul, tabs[0]);
-    __syncthreads();
-    int cur = 0;
-    for (; ul < user_count; ul += gridDim.x, cur ^= 1) {
-        const int64_t nxt = ul + gridDim.x;
-        if (nxt < user_count) td_build_tables<PAIRS>(ws, a, a.user_begin + nxt, tabs[cur ^ 1]);   // in front of this user's stores
-        const float2* brx = tabs[cur];
-        const float2* atx = brx + (size_t)a.m_rx * P;
-        float2* __restrict__ o = out + (size_t)ul * per_user;
-        unsigned sidx = s_first, m = m_first, r = r_first;
-        for (size_t i = e0; i < per_user; i += STEP) {
-            const float2 b = brx[r * uP + sidx], t = atx[m * uP + sidx];
-            const float2 v0 = make_float2(b.x * t.x - b.y * t.y, b.x * t.y + b.y * t.x);
-            if (PAIRS) {
-                unsigned s1 = sidx + 1, m1 = m, r1 = r;
-                if (s1 == uP) { s1 = 0; if (++m1 == uT) { m1 = 0; ++r1; } }
-                const float2 b1 = brx[r1 * uP + s1], t1 = atx[m1 * uP + s1];    // i + 1 < per_user: per_user is even
-                f4v w = {v0.x, v0.y, b1.x * t1.x - b1.y * t1.y, b1.x * t1.y + b1.y * t1.x};
-                __builtin_nontemporal_store(w, reinterpret_cast<f4v*>(o + i));
-            } else {
-                o[i] = v0;
-            }
-            sidx += ds;
-            unsigned carry = 0;
-            if (sidx >= uP) { sidx -= uP; carry = 1; }
-            m += dm + carry;
-            r += dr;
-            if (m >= uT) { m -= uT; ++r; }
-            if (m >= uT) { m -= uT; ++r; }                                      // dm + carry can reach m_tx
-        }
-        __syncthreads();                                    // tables of the next user complete; this user's are free
-    }
-}
-
 int launch_channels_td(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
                        float2* out, hipStream_t stream) {
     if (user_count == 0 || ws.P == 0) return DMX_OK;
@@ -200,19 +119,7 @@ int launch_channels_td(const dmx_params& prm, const WsView& ws, int64_t user_beg
     a.bs_mh = prm.bs_shape[0];
     const size_t smem = (size_t)(a.m_rx + a.m_tx) * ws.P * 8;
     const bool pairs = ((size_t)a.m_rx * a.m_tx * ws.P) % 2 == 0 && ((uintptr_t)out % 16) == 0 && !tuning_set("DMX_TD_NARROW");   // tuning build only: 8-byte stores
-    const bool persist = 2 * smem <= 64 * 1024 && tuning_int("DMX_TD_PERSIST", 1) == 1;   // tuning build only: 0 = one workgroup per user
-    if (persist) {
-        const void* kfn = pairs ? reinterpret_cast<const void*>(k4_td_persist<true>) : reinterpret_cast<const void*>(k4_td_persist<false>);
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, 2 * smem) != hipSuccess || per_cu < 1) {
-            (void)hipGetLastError();
-            per_cu = 1;
-        }
-        int64_t grid = (int64_t)device_cu_count() * per_cu;
-        if (grid > user_count) grid = user_count;
-        if (pairs) hipLaunchKernelGGL(k4_td_persist<true>, dim3((unsigned)grid), dim3(256), 2 * smem, stream, ws, a, out, user_count);
-        else hipLaunchKernelGGL(k4_td_persist<false>, dim3((unsigned)grid), dim3(256), 2 * smem, stream, ws, a, out, user_count);
-    } else if (smem <= 64 * 1024 && pairs)
+    if (smem <= 64 * 1024 && pairs)
         hipLaunchKernelGGL(k4_td_tab<true>, dim3((unsigned)user_count), dim3(256), smem, stream, ws, a, out);
     else if (smem <= 64 * 1024)
         hipLaunchKernelGGL(k4_td_tab<false>, dim3((unsigned)user_count), dim3(256), smem, stream, ws, a, out);
