@@ -1,4 +1,6 @@
 #!/bin/bash
+# needs the tuning build: make -C deepmimo_amd/csrc alt ALTFLAGS=-DDMX_TUNING_HOOKS, then DMX_LIB_PATH=deepmimo_amd/lib/alt/libdeepmimo_amd.so
+# (the shipped library reads no environment variable, csrc/dmx_tuning.h)
 # second sweep of the folded kernel: the edges of its dispatch region (K 16..32, 48-64 pairs) and the chunk size
 cd "${GRAFT_REPO_ROOT:-.}" || exit 1
 for shape in "8 1 1 1 25 4" "8 1 1 1 25 8" "8 1 1 1 25 12" "8 4 1 1 25 8" "8 4 1 1 25 12" "8 8 1 1 25 8" "8 8 1 1 25 16" "8 8 1 1 25 32" "8 1 1 1 25 16" "8 1 1 1 25 24" "8 2 1 1 25 16" "8 4 1 1 25 16" "8 4 1 1 25 24" "8 6 1 1 25 64" "8 6 1 1 25 128" "8 6 1 1 25 256" "8 6 1 1 25 512" "8 8 1 1 25 128" "8 8 1 1 25 256" "4 1 1 1 25 64" "2 1 1 1 25 512" "1 1 1 1 25 512"; do

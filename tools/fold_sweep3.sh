@@ -1,4 +1,6 @@
 #!/bin/bash
+# needs the tuning build: make -C deepmimo_amd/csrc alt ALTFLAGS=-DDMX_TUNING_HOOKS, then DMX_LIB_PATH=deepmimo_amd/lib/alt/libdeepmimo_amd.so
+# (the shipped library reads no environment variable, csrc/dmx_tuning.h)
 # folded kernel with one table set per workgroup (33-128 antenna pairs) against the plain matrix-core kernel, and the two
 # table modes against each other at 32 pairs
 cd "${GRAFT_REPO_ROOT:-.}" || exit 1

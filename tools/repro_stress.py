@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Bit-reproducibility stress: N launches of one stage-2 kernel on the same prepared users, per-user checksums against
-the first launch.  `python tools/repro_stress.py [--shape 8x1] [--K 512] [--users 200000] [--launches 100] [--variant 0]`"""
+the first launch.  `python tools/repro_stress.py [--bs 8x1] [--K 512] [--users 200000] [--launches 100] [--variant 0]`
+The first mismatch is saved and classified (tests/_repro_dump.py -> gpurun_out/repro_dump_stress_tool.{npz,json}): one
+failure is enough, this is not a tool for re-running until something fails."""
 import argparse
 import os
 import sys
@@ -25,6 +27,7 @@ def main():
     ap.add_argument("--all-valid", action="store_true")
     ap.add_argument("--beams", type=int, default=0, help="stress dmx_beam_power with this many steering beams instead")
     ap.add_argument("--rx-filter", action="store_true")
+    ap.add_argument("--adaptive", action="store_true", help="DMX_FLAG_ADAPTIVE_TERMS (default: three product terms)")
     args = ap.parse_args()
     bs = [int(x) for x in args.bs.split("x")]
     ue = [int(x) for x in args.ue.split("x")]
@@ -37,7 +40,7 @@ def main():
     if args.rx_filter:
         p.ofdm.rx_filter = 1
     eng = ChannelEngine(0)
-    prep = eng.prepare(eng.upload_rays(rays), p, want_side=True)
+    prep = eng.prepare(eng.upload_rays(rays), p, want_side=True, adaptive_terms=args.adaptive)
     nk = prep.side["num_paths"].cpu().numpy()
     if args.beams:
         F = np.stack([dm.steering_vec(np.array(bs), phi=a).ravel() for a in np.linspace(-60, 60, args.beams)])
@@ -68,6 +71,9 @@ def main():
     for it in range(args.launches):
         H = eng.channels(prep, out=H, variant=args.variant)
         bad = torch.nonzero(checksums(H) != ref).flatten().cpu().numpy()
+        if len(bad) and not total:
+            from tests._repro_dump import dump_from_checksums
+            print("saved:", dump_from_checksums("stress_tool", eng, prep, p, rays, H, bad, variant=args.variant))
         total += len(bad)
         for u in bad[:3]:
             msg = f"launch {it}: user {u} (kept paths {nk[u]})"
@@ -76,7 +82,7 @@ def main():
                 idx = torch.nonzero(d.reshape(-1) > 0).flatten()
                 msg += f": {len(idx)} elements differ, first flat indices {idx[:4].tolist()}, max |d| / peak {float(d.max() / H0[u].abs().max()):.2e}"
             print(msg)
-    print(f"bs {args.bs} ue {args.ue} K {args.K} variant {args.variant} env NO_ADAPTIVE={os.environ.get('DMX_NO_ADAPTIVE')}: "
+    print(f"bs {args.bs} ue {args.ue} K {args.K} variant {args.variant} adaptive_terms={args.adaptive}: "
           f"{total} differing user-launches in {args.launches} launches x {n} users")
 
 
