@@ -81,6 +81,21 @@ __device__ __forceinline__ void fold_split2(float x0, float x1, fh2& hi, fh2& lo
 // reads element 0 whatever i is with this compiler; through a by-value parameter it is the element asked for
 __device__ __forceinline__ unsigned fold_bits(float x) { return __builtin_bit_cast(unsigned, x); }
 
+// max over the 32 path lanes (both half-waves hold the same values): four DPP steps give every lane its 16-lane row's
+// maximum, two lane reads combine the rows - 7 vector instructions and no LDS round trip (five ds_bpermute steps before)
+__device__ __forceinline__ float fold_max_paths(float v) {
+    int x = __builtin_bit_cast(int, v);
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false)));    // quad_perm [1,0,3,2]
+    x = __builtin_bit_cast(int, v);
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false)));    // quad_perm [2,3,0,1]
+    x = __builtin_bit_cast(int, v);
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false)));   // row_half_mirror
+    x = __builtin_bit_cast(int, v);
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false)));   // row_mirror
+    x = __builtin_bit_cast(int, v);
+    return fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 0)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 16)));
+}
+
 // a wave's own LDS writes are visible to its later reads (DS operations of one wave execute in order); the compiler
 // only has to be kept from moving accesses across this point
 __device__ __forceinline__ void wave_lds_sync() {
@@ -460,15 +475,16 @@ __global__ __launch_bounds__(256, 4) void k2_fd_fold(WsView ws, FoldArgs a, floa
         const double q = ok ? (double)ws.dn[rb] * a.inv_n : 0.0;
         const double rxy = ok ? ws.rx_y[rb] : 0.0, rxz = ok ? ws.rx_z[rb] : 0.0;
         const double txy = ok ? ws.tx_y[rb] : 0.0, txz = ok ? ws.tx_z[rb] : 0.0;
-        float m = fmaxf(fabsf(cr), fabsf(ci));
-        for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-        // adaptive precision as in k2_channel_fd_mfma.hip (stage_item): a last K-step whose paths are all <= 2^-11 of the
-        // strongest one in amplitude is multiplied out in one f16 term (here: A'hi only is built for it)
-        const int l0w = ((n_act - 1) >> 3) << 3;
-        const float a2 = fmaf(cr, cr, ci * ci);
-        float m2 = a2, mw2 = lp >= l0w ? a2 : 0.f;
-        for (int off = 16; off > 0; off >>= 1) { m2 = fmaxf(m2, __shfl_xor(m2, off)); mw2 = fmaxf(mw2, __shfl_xor(mw2, off)); }
-        const bool last_weak = a.adaptive && l0w >= 8 && mw2 * 4194304.0f <= m2;
+        const float m = fold_max_paths(fmaxf(fabsf(cr), fabsf(ci)));
+        // opt-in adaptive precision as in k2_channel_fd_mfma.hip (stage_item): a last K-step whose paths are all <= 2^-11 of
+        // the strongest one in amplitude is multiplied out in one f16 term (here: A'hi only is built for it)
+        bool last_weak = false;
+        if (a.adaptive) {                                                  // kernel-uniform
+            const int l0w = ((n_act - 1) >> 3) << 3;
+            const float a2 = fmaf(cr, cr, ci * ci);
+            const float m2 = fold_max_paths(a2), mw2 = fold_max_paths(lp >= l0w ? a2 : 0.f);
+            last_weak = l0w >= 8 && mw2 * 4194304.0f <= m2;
+        }
         int e;
         (void)frexpf(m, &e);                                               // m = f * 2^e, f in [0.5, 1)
         const float gs = ldexpf(1.0f, 10 - e);                             // max |c| component -> [512, 1024)
