@@ -85,41 +85,11 @@ __device__ __forceinline__ void np_sincosf(float x, float& s_out, float& c_out) 
     c_out = (iqc & 2) ? -cv : cv;
 }
 
-// float64 sin / cos for the LEAN instantiations (nothing but the channel depends on them: no angle output, no FoV
-// compare, no dipole gain - those keep the library call, whose last-bit behaviour the FoV masks were validated with).
-// Cody-Waite reduction by pi/2 in two constants (exact for |k| < 2^20) and the fdlibm kernels (|error| < 1e-16 on
-// [-pi/4, pi/4]): ~20 float64 operations against ~100 of the library's double-double form - half of this kernel's
-// time was those two calls per path.  |x| >= 1e5 (never an angle in degrees times pi/180) takes the library call.
-__device__ __forceinline__ void sincos_lean(double x, double& s_out, double& c_out) {
-    if (!(fabs(x) < 1.0e5)) { sincos(x, &s_out, &c_out); return; }
-    const double k = rint(x * 6.36619772367581382433e-01);
-    double r = __builtin_fma(-k, 1.57079632673412561417e+00, x);
-    r = __builtin_fma(-k, 6.07710050650619224932e-11, r);
-    const double z = r * r;
-    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
-    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
-    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
-    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
-    const double sn = __builtin_fma(r * z, ps, r);
-    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
-    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
-    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
-    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
-    const double cs = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.0));
-    const int q = (int)k;
-    const double sv = (q & 1) ? cs : sn, cv = (q & 1) ? sn : cs;
-    s_out = (q & 2) ? -sv : sv;
-    c_out = ((q + 1) & 2) ? -cv : cv;
-}
-
 // geometry.py:284-310 for one path: the rotated direction as (cos zenith', re, im) with
 //   zenith' = arccos(zc)  (geometry.py:305-306),  azimuth' = angle(re + j im)  (geometry.py:308-310).
 // The angles themselves are only materialised when something needs them (side outputs, FoV, dipole
 // pattern); the array-response steps use sin(zenith') = sqrt(1 - zc^2), sin(azimuth') = im / |re + j im|
 // and cos(zenith') = zc, which are the same numbers without three float64 trig calls per array side.
-template <bool LEAN>
 __device__ __forceinline__ void rotate_dir(float el_deg, float az_deg, double sx, double cx, double sy,
                                            double cy, double rz, double& zc, double& re, double& im) {
     const float th32 = el_deg * D2R_F;
@@ -129,8 +99,7 @@ __device__ __forceinline__ void rotate_dir(float el_deg, float az_deg, double sx
     const double st = (double)st32, ct = (double)ct32;
     const double d = (double)ph32 - rz;
     double sd, cd;
-    if constexpr (LEAN) sincos_lean(d, sd, cd);
-    else sincos(d, &sd, &cd);
+    sincos(d, &sd, &cd);
     zc = cy * cx * ct + st * (sy * cx * cd - sx * sd);
     re = cy * st * cd - sy * ct;
     im = cy * sx * ct + st * (sy * sx * cd + cx * sd);
@@ -149,7 +118,7 @@ __device__ __forceinline__ void rotate_dir_zero(float el_deg, float az_deg, doub
     np_sincosf(th32, st32, ct32);
     const double st = (double)st32, ct = (double)ct32;
     double sd, cd;
-    sincos_lean((double)ph32, sd, cd);
+    sincos((double)ph32, &sd, &cd);
     zc = isnan(sd) ? sd : ct;
     re = st * cd;
     im = st * sd;
@@ -245,8 +214,8 @@ __global__ __launch_bounds__(256, LEAN ? 4 : 2) void k1_path_prep(PrepArgs a) {
             rotate_dir_zero(aod_el, aod_az, zc_t, re_t, im_t, sphi_t);
             rotate_dir_zero(aoa_el, aoa_az, zc_r, re_r, im_r, sphi_r);
         } else {
-            rotate_dir<LEAN>(aod_el, aod_az, a.bsx, a.csx, a.bsy, a.csy, a.brz, zc_t, re_t, im_t);
-            rotate_dir<LEAN>(aoa_el, aoa_az, usx, ucx, usy, ucy, urz, zc_r, re_r, im_r);
+            rotate_dir(aod_el, aod_az, a.bsx, a.csx, a.bsy, a.csy, a.brz, zc_t, re_t, im_t);
+            rotate_dir(aoa_el, aoa_az, usx, ucx, usy, ucy, urz, zc_r, re_r, im_r);
         }
         // arccos is NaN outside [-1, 1]; np.angle is NaN only for NaN input
         double th_t = (isnan(zc_t) || fabs(zc_t) > 1.0) ? nan64 : 0.0, ph_t = (isnan(re_t) || isnan(im_t)) ? nan64 : 0.0;
