@@ -108,96 +108,6 @@ __global__ __launch_bounds__(256) void k4_td_tab(WsView ws, TdArgs a, float2* __
     }
 }
 
-// Row form (round 3).  k4_td_tab walks the user's block as a flat element stream: per PAIR of elements four 8-byte
-// LDS reads, the carries of a (slot, tx, rx) counter and eight multiplies - ~25 vector instructions per 16 bytes
-// stored, as many per byte as the folded frequency-domain kernel executes, and like it the kernel sat at 0.6 of HBM
-// on instruction issue.  Here a half-wave lane owns half of one (rx, tx) ROW of P slots: both factor-table rows are read
-// with 16-byte LDS loads (two slots each; table rows padded to an odd multiple of 16 bytes: conflict-free), two packed
-// complex products, the results parked in a per-wave LDS tile [32 rows][P] in output order, and the tile then leaves as
-// a flat stream of 16-byte non-temporal stores (a wave instruction writes 1 KiB of consecutive addresses) - ~8 vector
-// instructions per 16 bytes.  One workgroup per user as before; needs an even element count per user (16-byte aligned
-// user blocks) and tables + tiles within 64 KB, else the forms above run.
-typedef float tdv2 __attribute__((ext_vector_type(2)));
-typedef float tdv4 __attribute__((ext_vector_type(4)));
-__host__ __device__ inline int td_row_bytes(int P) {
-    int b = (P * 8 + 15) / 16 * 16;
-    if (((b / 16) & 1) == 0) b += 16;
-    return b;
-}
-__host__ __device__ inline size_t td_rows_lds_bytes(int m_rx, int m_tx, int P) {
-    return (size_t)(m_rx + m_tx) * td_row_bytes(P) + (size_t)4 * 32 * P * 8;
-}
-
-__global__ __launch_bounds__(256) void k4_td_rows(WsView ws, TdArgs a, float2* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int P = ws.P;
-    const int TS = td_row_bytes(P);                                  // bytes per table row
-    unsigned char* brx = smem;                                       // [m_rx][TS]  c_s a_rx[r,s]
-    unsigned char* atx = smem + (size_t)a.m_rx * TS;                 // [m_tx][TS]  a_tx[t,s]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned char* tile = smem + (size_t)(a.m_rx + a.m_tx) * TS + (size_t)wave * 32 * P * 8;   // [32][P] float2, output order
-    const int64_t u = a.user_begin + blockIdx.x;
-    const int rows_total = a.m_rx * a.m_tx;
-    const size_t per_user = (size_t)rows_total * P;
-    float2* __restrict__ o = out + (size_t)blockIdx.x * per_user;
-    const int n_keep = ws.n_keep[u];
-    const size_t rb = (size_t)u * P;
-    const int slots_row = TS / 8;                                    // table slots per row incl. the zero padding
-    for (int i = tid; i < (a.m_rx + a.m_tx) * slots_row; i += 256) {
-        const int e = i / slots_row, s = i - e * slots_row;          // e < m_rx: receive element, else transmit element
-        float2 v = make_float2(0.f, 0.f);
-        if (s < n_keep) {
-            float sn, cs;
-            if (e < a.m_rx) {
-                sincos_rev(frac_rev((double)(e % a.ue_mh) * ws.rx_y[rb + s] + (double)(e / a.ue_mh) * ws.rx_z[rb + s]), sn, cs);
-                const float cr = ws.c_re[rb + s], ci = ws.c_im[rb + s];
-                v = make_float2(cr * cs - ci * sn, cr * sn + ci * cs);
-            } else {
-                const int t = e - a.m_rx;
-                sincos_rev(frac_rev((double)(t % a.bs_mh) * ws.tx_y[rb + s] + (double)(t / a.bs_mh) * ws.tx_z[rb + s]), sn, cs);
-                v = make_float2(cs, sn);
-            }
-        }
-        *reinterpret_cast<float2*>(smem + (size_t)e * TS + (size_t)s * 8) = v;   // the two tables are contiguous
-    }
-    __syncthreads();
-    // half-wave h of a wave takes slots [h * sh, min(P, (h + 1) * sh)), sh = ceil(P / 2) rounded up to even
-    const int rl = lane & 31, h = lane >> 5;
-    const int sh = ((P + 1) / 2 + 1) & ~1;
-    const int s0 = h * sh, s1 = (s0 + sh) < P ? (s0 + sh) : P;
-    for (int rb0 = wave * 32; rb0 < rows_total; rb0 += 128) {
-        const int nrows = (rows_total - rb0) < 32 ? (rows_total - rb0) : 32;
-        const int row = rb0 + rl;
-        if (rl < nrows) {
-            const int r = row / a.m_tx, m = row - r * a.m_tx;
-            const unsigned char* bp = brx + (size_t)r * TS;
-            const unsigned char* tp = atx + (size_t)m * TS;
-            unsigned char* dst = tile + (size_t)rl * P * 8;
-#pragma unroll 4
-            for (int s = s0; s < s1; s += 2) {                       // two slots per 16-byte read; a pad slot reads as zero
-                const tdv4 b = *reinterpret_cast<const tdv4*>(bp + s * 8);
-                const tdv4 t = *reinterpret_cast<const tdv4*>(tp + s * 8);
-                const tdv2 v0 = __builtin_elementwise_fma(tdv2{-b[1], b[1]}, tdv2{t[1], t[0]}, tdv2{b[0], b[0]} * tdv2{t[0], t[1]});
-                *reinterpret_cast<tdv2*>(dst + s * 8) = v0;
-                if (s + 1 < s1) {
-                    const tdv2 v1 = __builtin_elementwise_fma(tdv2{-b[3], b[3]}, tdv2{t[3], t[2]}, tdv2{b[2], b[2]} * tdv2{t[2], t[3]});
-                    *reinterpret_cast<tdv2*>(dst + (s + 1) * 8) = v1;
-                }
-            }
-        }
-        // the wave's own LDS writes are visible to its own later reads (in-order DS queue); keep the compiler from reordering
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        const int n16 = nrows * P / 2;                               // 16-byte pieces of this tile (nrows * P is even: see launch)
-        tdv4* __restrict__ og = reinterpret_cast<tdv4*>(o + (size_t)rb0 * P);
-#pragma unroll 4
-        for (int i = lane; i < n16; i += 64)
-            __builtin_nontemporal_store(*reinterpret_cast<const tdv4*>(tile + (size_t)i * 16), og + i);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
 int launch_channels_td(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
                        float2* out, hipStream_t stream) {
     if (user_count == 0 || ws.P == 0) return DMX_OK;
@@ -209,13 +119,7 @@ int launch_channels_td(const dmx_params& prm, const WsView& ws, int64_t user_beg
     a.bs_mh = prm.bs_shape[0];
     const size_t smem = (size_t)(a.m_rx + a.m_tx) * ws.P * 8;
     const bool pairs = ((size_t)a.m_rx * a.m_tx * ws.P) % 2 == 0 && ((uintptr_t)out % 16) == 0 && !tuning_set("DMX_TD_NARROW");   // tuning build only: 8-byte stores
-    // row form: every 32-row tile must hold an even number of elements (32 P is; the last tile's (rows mod 32) P too
-    // when the user's element count is even) so that it leaves in whole 16-byte pieces
-    const size_t smem_rows = td_rows_lds_bytes(a.m_rx, a.m_tx, ws.P);
-    const bool rows_ok = pairs && smem_rows <= 64 * 1024 && (((size_t)a.m_rx * a.m_tx) % 32 * ws.P) % 2 == 0 && tuning_int("DMX_TD_ROWS", 1) == 1;
-    if (rows_ok)
-        hipLaunchKernelGGL(k4_td_rows, dim3((unsigned)user_count), dim3(256), smem_rows, stream, ws, a, out);
-    else if (smem <= 64 * 1024 && pairs)
+    if (smem <= 64 * 1024 && pairs)
         hipLaunchKernelGGL(k4_td_tab<true>, dim3((unsigned)user_count), dim3(256), smem, stream, ws, a, out);
     else if (smem <= 64 * 1024)
         hipLaunchKernelGGL(k4_td_tab<false>, dim3((unsigned)user_count), dim3(256), smem, stream, ws, a, out);
