@@ -176,6 +176,15 @@ SHAPES_FOLD = [
     (12, 25, [2, 1], [1, 1], 1024, list(range(1024)), dict(all_valid=True, max_delay=90e-6)),   # 2 pairs: 16 blocks per tile
     (11, 3, [8, 1], [1, 1], 64, list(range(10, 43)), {}),                               # K = 33: a lone subcarrier in the last block
     (10, 25, [1, 1], [1, 1], 4096, list(range(4096)), dict(all_valid=True, max_delay=300e-6)),  # one pair, 4096 subcarriers
+    # round 3: power-of-two pair counts take the scalar-row-offset stores; tiles that hold rows past the chunk or a
+    # partial last block take their checked form - every power of two with a tail, the half-wave row term in each regime
+    (9, 25, [4, 1], [1, 1], 64, list(range(50)), {}),                                   # 4 pairs, K % 16 = 2: lane >> 5 moves the block
+    (9, 12, [2, 1], [1, 1], 64, list(range(3, 24)), {}),                                # 2 pairs, K = 21
+    (9, 25, [1, 1], [1, 1], 64, list(range(17)), {}),                                   # 1 pair, K = 17
+    (9, 25, [4, 4], [1, 1], 128, list(range(0, 80, 2)), dict(all_valid=True)),          # 16 pairs, K = 40 (tail 8), stride 2
+    (7, 25, [8, 4], [1, 1], 64, list(range(53)), {}),                                   # 32 pairs, K = 53 (tail 5): one block per tile
+    (6, 25, [8, 4], [2, 1], 128, list(range(72)), dict(bs_rot=[0, 0, 30])),             # 64 pairs (shared tables), K = 72 (tail 8)
+    (5, 25, [8, 8], [2, 1], 64, list(range(19)), {}),                                   # 128 pairs, K = 19: a block spans four tiles
 ]
 
 
