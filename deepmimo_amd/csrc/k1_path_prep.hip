@@ -61,7 +61,9 @@ static constexpr double LIGHTSPEED = 299792458.0;           // deepmimo_v3/const
 // (tests/test_oracle_golden.py::test_numpy_f32_sincos_model).  |x| beyond the routine's range
 // (7e4) falls back to sinf / cosf like NumPy falls back to libm.
 __device__ __forceinline__ void np_sincosf(float x, float& s_out, float& c_out) {
-    if (!(fabsf(x) <= 71476.0625f)) { s_out = sinf(x); c_out = cosf(x); return; }
+    // NaN - "no path": the padding lanes of every wave and most paths of a ray-traced user - must take the polynomial (it
+    // propagates NaN like np.sin does), not this branch: the wave would execute libm's large-argument sinf AND cosf for it
+    if (fabsf(x) > 71476.0625f) { s_out = sinf(x); c_out = cosf(x); return; }
     float q = x * 0x1.45f306p-1f;
     q = (q + 0x1.8p+23f) - 0x1.8p+23f;                       // round to nearest integer
     float r = fmaf(q, -0x1.921fb0p+00f, x);
@@ -85,11 +87,41 @@ __device__ __forceinline__ void np_sincosf(float x, float& s_out, float& c_out) 
     c_out = (iqc & 2) ? -cv : cv;
 }
 
+// float64 sin / cos for the LEAN instantiations (nothing but the channel depends on them: no angle output, no FoV
+// compare, no dipole gain - those keep the library call, whose last-bit behaviour the FoV masks were validated with).
+// Cody-Waite reduction by pi/2 in two constants (exact for |k| < 2^20) and the fdlibm kernels: 2.2e-16 against long
+// double on 2e7 arguments.  |x| >= 1e5 (never an angle in degrees times pi/180) takes the library call; NaN - the padding
+// lanes of every wave - must NOT: a first version sent NaN there too and every wave executed both forms.
+__device__ __forceinline__ void sincos_lean(double x, double& s_out, double& c_out) {
+    if (fabs(x) >= 1.0e5) { sincos(x, &s_out, &c_out); return; }
+    const double k = rint(x * 6.36619772367581382433e-01);
+    double r = __builtin_fma(-k, 1.57079632673412561417e+00, x);
+    r = __builtin_fma(-k, 6.07710050650619224932e-11, r);
+    const double z = r * r;
+    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    const double sn = __builtin_fma(r * z, ps, r);
+    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    const double cs = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.0));
+    const int q = (int)k;                                    // NaN -> 0: the NaN of sn / cs goes through
+    const double sv = (q & 1) ? cs : sn, cv = (q & 1) ? sn : cs;
+    s_out = (q & 2) ? -sv : sv;
+    c_out = ((q + 1) & 2) ? -cv : cv;
+}
+
 // geometry.py:284-310 for one path: the rotated direction as (cos zenith', re, im) with
 //   zenith' = arccos(zc)  (geometry.py:305-306),  azimuth' = angle(re + j im)  (geometry.py:308-310).
 // The angles themselves are only materialised when something needs them (side outputs, FoV, dipole
 // pattern); the array-response steps use sin(zenith') = sqrt(1 - zc^2), sin(azimuth') = im / |re + j im|
 // and cos(zenith') = zc, which are the same numbers without three float64 trig calls per array side.
+template <bool LEAN>
 __device__ __forceinline__ void rotate_dir(float el_deg, float az_deg, double sx, double cx, double sy,
                                            double cy, double rz, double& zc, double& re, double& im) {
     const float th32 = el_deg * D2R_F;
@@ -99,7 +131,15 @@ __device__ __forceinline__ void rotate_dir(float el_deg, float az_deg, double sx
     const double st = (double)st32, ct = (double)ct32;
     const double d = (double)ph32 - rz;
     double sd, cd;
-    sincos(d, &sd, &cd);
+    if constexpr (LEAN) {
+        sincos_lean(d, sd, cd);
+    } else {
+        // the library call on a finite stand-in for NaN ("no path": padding lanes, most paths of a ray-traced user), so that
+        // no wave walks its large-argument reduction for them; finite arguments get the very same bits as before
+        const bool bad = isnan(d);
+        sincos(bad ? 0.0 : d, &sd, &cd);
+        if (bad) { sd = d; cd = d; }
+    }
     zc = cy * cx * ct + st * (sy * cx * cd - sx * sd);
     re = cy * st * cd - sy * ct;
     im = cy * sx * ct + st * (sy * sx * cd + cx * sd);
@@ -118,7 +158,7 @@ __device__ __forceinline__ void rotate_dir_zero(float el_deg, float az_deg, doub
     np_sincosf(th32, st32, ct32);
     const double st = (double)st32, ct = (double)ct32;
     double sd, cd;
-    sincos((double)ph32, &sd, &cd);
+    sincos_lean((double)ph32, sd, cd);
     zc = isnan(sd) ? sd : ct;
     re = st * cd;
     im = st * sd;
@@ -214,8 +254,8 @@ __global__ __launch_bounds__(256, LEAN ? 4 : 2) void k1_path_prep(PrepArgs a) {
             rotate_dir_zero(aod_el, aod_az, zc_t, re_t, im_t, sphi_t);
             rotate_dir_zero(aoa_el, aoa_az, zc_r, re_r, im_r, sphi_r);
         } else {
-            rotate_dir(aod_el, aod_az, a.bsx, a.csx, a.bsy, a.csy, a.brz, zc_t, re_t, im_t);
-            rotate_dir(aoa_el, aoa_az, usx, ucx, usy, ucy, urz, zc_r, re_r, im_r);
+            rotate_dir<LEAN>(aod_el, aod_az, a.bsx, a.csx, a.bsy, a.csy, a.brz, zc_t, re_t, im_t);
+            rotate_dir<LEAN>(aoa_el, aoa_az, usx, ucx, usy, ucy, urz, zc_r, re_r, im_r);
         }
         // arccos is NaN outside [-1, 1]; np.angle is NaN only for NaN input
         double th_t = (isnan(zc_t) || fabs(zc_t) > 1.0) ? nan64 : 0.0, ph_t = (isnan(re_t) || isnan(im_t)) ? nan64 : 0.0;
@@ -276,7 +316,7 @@ __global__ __launch_bounds__(256, LEAN ? 4 : 2) void k1_path_prep(PrepArgs a) {
         const bool valid = used && !isnan(pw);               // channel.py:260
         const float ph32 = phase * D2R_F;                    // np.deg2rad(float32)
         float e_re, e_im;
-        sincosf(ph32, &e_im, &e_re);                         // complex64 exp: float32 cos / sin
+        np_sincosf(ph32, e_im, e_re);                        // complex64 exp: NumPy's float32 cos / sin (and NaN-cheap, see there)
         const bool ang_ok = !isnan(th_t) && !isnan(th_r);    // geometry.py:65 zeroes NaN-zenith columns
         float c_re, c_im, dn = 0.0f;
         bool keep;
