@@ -11,7 +11,7 @@ shift || true
 cd "${GRAFT_REPO_ROOT:-.}" || exit 1
 export TMPDIR=/tmp
 out=gpurun_out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -- python3 bench.py --steps 5 --warmup 2 --cpu-users 0 --skip-adaptive "$@" > $out/${tag}_stats.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -- python3 bench.py --steps 20 --warmup 5 --cpu-users 0 --skip-adaptive "$@" > $out/${tag}_stats.log 2>&1 || exit 1
 for set in WRITE_SIZE FETCH_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" "SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM"; do
     name=$(echo $set | tr ' ' '_' | cut -c1-40)
     rocprofv3 --pmc $set --output-format csv -d $out/${tag}_pmc_$name -- python3 bench.py --steps 1 --warmup 0 --cpu-users 0 --skip-adaptive "$@" > $out/${tag}_pmc_$name.log 2>&1 || exit 1
