@@ -1290,3 +1290,39 @@ def test_array_response_product_matches_oracle():
     assert got.shape == want.shape == (40, 2, 8, 12) and got.dtype == np.complex128
     assert np.abs(got - want).max() < 1e-9
     assert np.array_equal(got == 0, want == 0)
+
+
+@pytest.mark.parametrize("adaptive", [False, True])
+@pytest.mark.parametrize("kind", ["fold_8x512", "fold_shared_64x128", "mfma_256x256", "beam_power"])
+def test_precision_flag_parity(kind, adaptive):
+    """dmx_params.flags (ABI 3): both arithmetic modes of the matrix-core kernels against the float64 oracle, on rays whose
+    powers span 80 dB (the opt-in one-term rule fires for most users).  Default: <= 3e-6 of a user's peak; with
+    DMX_FLAG_ADAPTIVE_TERMS: <= 1e-5 (stated tolerance 5e-5).  The flag is a field of the preparation's parameter block:
+    two engines' worth of state in one process, no environment involved."""
+    import deepmimo_amd as dm
+    from deepmimo_amd.engine import ChannelEngine
+    from oracle import oracle_np as onp
+    n, bs, ue, N = {"fold_8x512": (300, [8, 1], [1, 1], 512), "fold_shared_64x128": (120, [8, 8], [1, 1], 128),
+                    "mfma_256x256": (100, [8, 8], [2, 2], 256), "beam_power": (100, [8, 8], [2, 2], 256)}[kind]
+    rays = onp.synth_rays(n, 25, seed=123, all_valid=True)
+    p = dm.ChannelGenParameters()
+    p.bs_antenna.shape, p.ue_antenna.shape = np.array(bs), np.array(ue)
+    p.ofdm.subcarriers = N
+    p.ofdm.selected_subcarriers = np.arange(N)
+    op = onp.make_params(bs_antenna=dict(shape=bs), ue_antenna=dict(shape=ue), ofdm=dict(subcarriers=N, selected_subcarriers=np.arange(N)))
+    ref = onp.compute_channels(rays, op)["channel"].astype(np.complex128)
+    eng = ChannelEngine(0)
+    prep = eng.prepare(eng.upload_rays(rays), p, want_side="light", adaptive_terms=adaptive)
+    assert prep.params_struct.flags == (1 if adaptive else 0)
+    lim = 1e-5 if adaptive else 3e-6
+    if kind == "beam_power":
+        F = np.stack([dm.steering_vec(np.array(bs), phi=a).ravel() for a in np.linspace(-60, 60, 16)])
+        amp = eng.beam_power(prep, F)[0].cpu().numpy()
+        want = np.abs(np.einsum("bt,nrtk->nrbk", F, ref)).mean(axis=1).mean(axis=-1)
+        assert np.all(np.abs(amp - want) <= lim * want.max(axis=1, keepdims=True))
+        return
+    H = eng.channels(prep).cpu().numpy()
+    peak = np.abs(ref).reshape(n, -1).max(axis=1)
+    err = np.abs(H - ref).reshape(n, -1).max(axis=1) / peak
+    assert err.max() < lim, (kind, adaptive, err.max())
+    assert np.array_equal(prep.side["num_paths"].cpu().numpy(), np.full(n, 25))
