@@ -20,10 +20,14 @@
 //
 // Mapping: ONE WAVE owns one (user, chunk of <= CH subcarrier blocks) work item from start to end - no workgroup
 // barrier after the start-up tables, nothing shared between the four waves of a workgroup but the user-independent
-// row tables.  Per item: path records -> per-wave LDS tables (Ac, E1, q) -> E2' fragments in registers -> per 32-row
-// tile: At' fragments built in registers straight into the MFMA operand layout (4 complex products + 4 packed f16
-// splits per K-step), 3 MFMAs per K-step, 16 non-temporal buffer_store_dword (two 128-B row segments each; the row
-// offsets come from a table because row (a,p) lives at (p*K + 16a)*8 bytes).  Persistent grid.
+// row tables (33+ pairs: the four waves share one set of tables and split the row tiles).  Per item: path records ->
+// per-wave LDS tables (Ac, E1, q) -> E2' fragments in registers -> per 32-row tile and 8-path K-step ONE asm statement
+// that multiplies and splits the lane's table entries in place and loads the next K-step's (24 vector instructions, the
+// entries in v[112:127] by name), 3 MFMAs per K-step into two accumulators (even / odd K-steps), the result guard, a
+// packed add + scale, 16 non-temporal buffer_store_dword (two 128-B row segments each).  Row (a,p) lives at
+// (p*K + 16a)*8 bytes: scalar arithmetic in the store's soffset for a power-of-two pair count, a table otherwise.
+// Persistent grid, at most four workgroups per CU.  The shape of the tile loop is dictated by the round-2 incident:
+// see the comment in front of it and DESIGN.md section 4.
 #include "dmx_common.h"
 #include "dmx_tuning.h"
 
