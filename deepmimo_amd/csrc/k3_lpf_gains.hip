@@ -334,6 +334,214 @@ __global__ __launch_bounds__(256, K3_WAVES_PER_SIMD) void k3_lpf_fft_wave(WsView
     }
 }
 
+// ---- N = 512 (DeepMIMO's default OFDM size), one WAVE per USER -----------------------------------------------------
+// k3_lpf_fft_wave is generic in N and pays for it: 656 vector instructions per transform (profiles/r2_lpf_summary.txt),
+// which is its time (VALU issue 3.2 of 4.3 ms at the headline shape).  With N fixed at 512 = 8^3 and a lane holding the
+// eight points d = lane + 64 r of its transform:
+//   * the taps a lane generates are exactly the eight inputs of ITS butterfly of the first Stockham pass - no LDS round
+//     trip for the taps, and that pass has no twiddles;
+//   * the twiddles of passes 2 and 3 depend on the lane only (exp(-j 2pi (lane & 7) r / 64), exp(-j 2pi lane r / 512)):
+//     28 registers filled once per wave - no table, no lookups, no address arithmetic;
+//   * a wave's reads of a pass are all issued before its writes and LDS serves a wave in order: ONE buffer per wave,
+//     transformed in place;
+//   * the last pass leaves bins lane + 64 r in the lane - when the selected subcarriers are 0 .. K-1 (IDENT) they are
+//     scaled, split and stored from registers; other selections go through the buffer once more;
+//   * sin(pi (d - dn)) = -(-1)^d sin(pi dn) and (-1)^d = (-1)^lane for every point of the lane: tap = (c * S) / (d - dn)
+//     with one per-lane S per path, i.e. subtract, reciprocal, one packed multiply per tap;
+//   * a wave owns a USER (all its paths in turn): no workgroup barrier, no 7 / 6 / 6 / 6 imbalance of 25 paths over 4 waves.
+//   * Doppler (float64 phases per tap) is its own instantiation: its registers would halve the others' occupancy.
+// Packed-fp32 forms the compiler does not select (it keeps a swizzled copy of every twiddle - 56 registers instead of 28 -
+// negates with v_xor and moves halves around for the multiplications by -j: 3 instructions per complex product, 37 per
+// radix-8 butterfly).  op_sel / op_sel_hi pick the 32-bit half that feeds the low / high result, neg_lo / neg_hi negate it.
+// None of these reads a transcendental's result directly (taps and Doppler phasors go through compiler-selected
+// multiplies first), and there are no matrix-core instructions in this file.
+__device__ __forceinline__ float2 cmul_pk(float2 a, float2 b) {              // a * b: 2 instructions, b as it is
+    kv2 r;
+    const kv2 av = {a.x, a.y}, bv = {b.x, b.y};
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=&v"(r) : "v"(av), "v"(bv));
+    return make_float2(r[0], r[1]);
+}
+__device__ __forceinline__ float2 cadd_mj(float2 a, float2 b) {              // a + (-j) b = (a.x + b.y, a.y - b.x)
+    kv2 r;
+    const kv2 av = {a.x, a.y}, bv = {b.x, b.y};
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(av), "v"(bv));
+    return make_float2(r[0], r[1]);
+}
+__device__ __forceinline__ float2 csub_mj(float2 a, float2 b) {              // a - (-j) b = (a.x - b.y, a.y + b.x)
+    kv2 r;
+    const kv2 av = {a.x, a.y}, bv = {b.x, b.y};
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(av), "v"(bv));
+    return make_float2(r[0], r[1]);
+}
+__device__ __forceinline__ float2 rot1_pk(float2 b) {                        // sqrt(2) e^{-j pi/4} b = (x + y, y - x)
+    kv2 r;
+    const kv2 bv = {b.x, b.y};
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(bv));
+    return make_float2(r[0], r[1]);
+}
+__device__ __forceinline__ float2 rot3_pk(float2 b) {                        // sqrt(2) e^{-j 3pi/4} b = (y - x, -x - y)
+    kv2 r;
+    const kv2 bv = {b.x, b.y};
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[1,0] neg_hi:[1,1]" : "=v"(r) : "v"(bv));
+    return make_float2(r[0], r[1]);
+}
+__device__ __forceinline__ float2 cscale(float2 a, float s) { const kv2 r = kv2{a.x, a.y} * s; return make_float2(r[0], r[1]); }
+// radix-8 butterfly, 28 packed instructions (dft_small<8> with the -j factors folded into the additions)
+__device__ __forceinline__ void dft8_pk(float2 (&v)[8]) {
+    constexpr float H = 0.70710678118654752f;
+    float2 a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a[k] = caddf(v[k], v[k + 4]); b[k] = csubf(v[k], v[k + 4]); }
+    const float2 b1 = cscale(rot1_pk(b[1]), H), b3 = cscale(rot3_pk(b[3]), H);
+    const float2 t0 = caddf(a[0], a[2]), t1 = csubf(a[0], a[2]), t2 = caddf(a[1], a[3]), d = csubf(a[1], a[3]);
+    v[0] = caddf(t0, t2); v[2] = cadd_mj(t1, d); v[4] = csubf(t0, t2); v[6] = csub_mj(t1, d);
+    const float2 u0 = cadd_mj(b[0], b[2]), u1 = csub_mj(b[0], b[2]), u2 = caddf(b1, b3), e = csubf(b1, b3);
+    v[1] = caddf(u0, u2); v[3] = cadd_mj(u1, e); v[5] = csubf(u0, u2); v[7] = csub_mj(u1, e);
+}
+
+template <bool PACK>
+__device__ __forceinline__ void store_gain(float2* grow, uint2* prow, int k, float2 g, float m1) {
+    if constexpr (PACK) {
+        h2 hi, lo;
+        split2_f16(g.x, g.y, hi, lo, m1);
+        prow[k] = make_uint2(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo));
+    } else {
+        grow[k] = g;
+    }
+}
+template <bool IDENT, bool PACK, bool DOPPLER>
+__global__ __launch_bounds__(256) void k3_lpf_fft512(WsView ws, LpfArgs a, int64_t user_count) {
+    constexpr int N = 512;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float2* X = reinterpret_cast<float2*>(smem) + (size_t)wave * lpf_buf_elems(N);
+    float2 tw2[8], tw3[8];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) {
+        float s, c;
+        sincos_rev(frac_rev(-(double)((lane & 7) * r) / 64.0), s, c);
+        tw2[r] = make_float2(c, s);
+        sincos_rev(frac_rev(-(double)(lane * r) / 512.0), s, c);
+        tw3[r] = make_float2(c, s);
+    }
+    // LDS positions of this lane: pass 1 writes elements 8 lane + r, reads of passes 2 / 3 take lane + 64 r, pass 2
+    // writes 64 (lane >> 3) + (lane & 7) + 8 r (Stockham autosort, see fft_pass)
+    float2* w1 = X + fpad(8 * lane);                       // + r: same pad for all eight
+    float2* rd = X + fpad(lane);                           // + 68 r
+    float2* w2 = X + fpad(64 * (lane >> 3) + (lane & 7));  // + 8 r: 64 g + k + 8 r < 64 g + 64, pad = 4 g + (k + 8 r) / 16
+    const int w2hi = (lane & 7);                           // (k + 8 r) >> 4 = r >> 1 for k < 8
+    (void)w2hi;
+    const float lanef = (float)lane;
+    const unsigned sgn = (lane & 1) ? 0u : 0x80000000u;    // S = (-1)^d * (-1) * s0: odd d -> +s0, even d -> -s0
+    int binreg[8];
+    if constexpr (!IDENT) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int k = lane + 64 * j; binreg[j] = k < a.K ? fpad(a.sc[k] & (N - 1)) : 0; }
+    }
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t ul = (int64_t)blockIdx.x * 4 + wave; ul < user_count; ul += nwaves) {
+        const int64_t u = a.user_begin + ul;
+        const int n_keep = ws.n_keep[u];
+        const size_t rb = (size_t)u * ws.P;
+        const bool lok = lane < n_keep;
+        const float dn_l = lok ? ws.dn[rb + lane] : 0.f;
+        float cr_l = lok ? ws.c_re[rb + lane] : 0.f, ci_l = lok ? ws.c_im[rb + lane] : 0.f;
+        const float dv_l = (lok && DOPPLER) ? ws.dop_v[rb + lane] : 0.f, da_l = (lok && DOPPLER) ? ws.dop_a[rb + lane] : 0.f;
+        // sin(pi dn) / pi per path, all paths in parallel (float64 sinpi: dn reaches thousands of samples)
+        const float s0_l = (float)(sinpi((double)dn_l) * (1.0 / LPF_PI));
+        if constexpr (PACK) {
+            // the operand scale k2_fd_mfma's stage_item derives for this user: max |c| component -> [512, 1024), two
+            // more bits of headroom for the sinc sum; a power of two, so scaling c instead of G changes nothing
+            float m = lane < (n_keep < 32 ? n_keep : 32) ? fmaxf(fabsf(cr_l), fabsf(ci_l)) : 0.f;
+            for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+            int e;
+            (void)frexpf(m, &e);
+            const float gsl = ldexpf(1.0f, 8 - e);
+            cr_l *= gsl; ci_l *= gsl;
+        }
+        for (int l = 0; l < n_keep; ++l) {
+            const float dnf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dn_l), l));
+            const float cr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cr_l), l));
+            const float ci = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ci_l), l));
+            const unsigned s0b = (unsigned)__builtin_amdgcn_readlane(__builtin_bit_cast(int, s0_l), l);
+            const float S = __builtin_bit_cast(float, s0b ^ sgn);
+            const kv2 cs = kv2{cr * S, ci * S};
+            const float x0 = lanef - dnf;                  // d - dn in float32: exact unless dn is tiny (then 6e-8 relative)
+            float2 v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const kv2 t = cs * __builtin_amdgcn_rcpf(x0 + (float)(64 * r));      // lane + 64 r is exact in float32, so is the sum
+                v[r] = make_float2(t[0], t[1]);
+            }
+            if (dnf == rintf(dnf) && dnf >= 0.f && dnf < (float)N) {                 // wave-uniform: np.sinc(0) = 1; s0 = 0, the other taps are 0
+                const int d0 = (int)dnf;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = (lane + 64 * r == d0) ? make_float2(cr, ci) : make_float2(0.f, 0.f);
+            }
+            if constexpr (DOPPLER) {
+                const double dv = (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv_l), l));
+                const double da = (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, da_l), l));
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const double tau = a.ts * (double)(lane + 64 * r);
+                    const double rev = -a.fc * (dv * tau / LPF_C0 + da * (tau * tau) / (2.0 * LPF_C0));
+                    float s, c;
+                    sincos_rev(frac_rev(rev), s, c);
+                    v[r] = cmulf(v[r], make_float2(c, s));
+                }
+            }
+            // pass 1 (Ns = 1): no twiddles; element 8 lane + r
+            dft8_pk(v);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) w1[r] = v[r];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            // pass 2 (Ns = 8)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = rd[68 * r];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) v[r] = cmul_pk(v[r], tw2[r]);
+            dft8_pk(v);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) w2[8 * r + (r >> 1)] = v[r];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            // pass 3 (Ns = 64): bins lane + 64 r
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = rd[68 * r];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) v[r] = cmul_pk(v[r], tw3[r]);
+            dft8_pk(v);
+            float2* grow = a.gtab + ((size_t)ul * ws.P + l) * a.K;
+            uint2* prow = reinterpret_cast<uint2*>(grow);
+            if constexpr (!IDENT) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");           // every lane has read its pass-3 inputs
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 8; ++r) rd[68 * r] = v[r];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = X[binreg[r]];
+            }
+            if (a.K == N) {                                                      // wave-uniform: no per-store guard
+#pragma unroll
+                for (int r = 0; r < 8; ++r) store_gain<PACK>(grow, prow, lane + 64 * r, v[r], ws.neg_one);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    if (lane + 64 * r < a.K) store_gain<PACK>(grow, prow, lane + 64 * r, v[r], ws.neg_one);
+            }
+            if constexpr (!IDENT) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");           // the gather has read X before the next path's pass 1
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
 int launch_channels_fd_lpf_contract(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
                                     const float2* gtab, float2* out, hipStream_t stream, bool packed);
 bool lpf_table_packed(const dmx_params& prm, const WsView& ws);
@@ -375,7 +583,27 @@ static int launch_channels_fd_lpf_once(const dmx_params& prm, const WsView& ws, 
         int log2n = 0;
         while ((1 << log2n) < a.N) ++log2n;
         const bool old = tuning_int("DMX_LPF_OLD_FFT", 0) == 1;       // tuning build only: the workgroup-per-user FFT
-        if (pow2 && a.N >= 64 && a.N <= 2048 && !old) {
+        if (a.N == 512 && ws.P <= 64 && !old && tuning_int("DMX_LPF_GENERIC_FFT", 0) != 1) {
+            // wave per user, N fixed (k3_lpf_fft512); tuning build only: DMX_LPF_GENERIC_FFT=1 takes the generic kernel below
+            a.pack = packed = lpf_table_packed(prm, ws) && tuning_int("DMX_LPF_FLOAT_TABLE", 0) != 1;
+            const bool ident = prm.sc_stride == 1 && (prm.sc_first & 511) == 0 && a.K <= 512;   // host promise: sc[k] = k (mod N)
+            const void* kfns[8] = {(const void*)k3_lpf_fft512<false, false, false>, (const void*)k3_lpf_fft512<false, false, true>,
+                                   (const void*)k3_lpf_fft512<false, true, false>,  (const void*)k3_lpf_fft512<false, true, true>,
+                                   (const void*)k3_lpf_fft512<true, false, false>,  (const void*)k3_lpf_fft512<true, false, true>,
+                                   (const void*)k3_lpf_fft512<true, true, false>,   (const void*)k3_lpf_fft512<true, true, true>};
+            const void* kfn = kfns[(ident ? 4 : 0) + (packed ? 2 : 0) + (a.doppler ? 1 : 0)];
+            const size_t smem = 4 * lpf_buf_elems(512) * 8;
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, smem) != hipSuccess || per_cu < 1) {
+                (void)hipGetLastError();
+                per_cu = 1;
+            }
+            int64_t grid = (int64_t)device_cu_count() * per_cu;
+            if (grid > (user_count + 3) / 4) grid = (user_count + 3) / 4;
+            void* kargs[] = {(void*)&ws, (void*)&a, (void*)&user_count};
+            hipError_t le = hipLaunchKernel(kfn, dim3((unsigned)grid), dim3(256), kargs, smem, stream);
+            if (le != hipSuccess) { set_error("k3_lpf_fft512 launch failed: %s", hipGetErrorString(le)); return DMX_ERR_LAUNCH; }
+        } else if (pow2 && a.N >= 64 && a.N <= 2048 && !old) {
             // tuning build only: DMX_LPF_FLOAT_TABLE=1 keeps the float table
             a.pack = packed = lpf_table_packed(prm, ws) && tuning_int("DMX_LPF_FLOAT_TABLE", 0) != 1;
             // wave-per-path radix-8 FFT; persistent workgroups (the twiddle table is built once per workgroup)

@@ -608,6 +608,42 @@ def test_rx_filter_fft_and_mfma_path(N, K):
         assert_channel_close(H, ref["channel"], what=f"lpf N={N} K={K} doppler={dop}")
 
 
+@pytest.mark.parametrize("arrays", ["mfma", "valu"])
+@pytest.mark.parametrize("selection", ["all512", "first200", "random100", "offset512"])
+def test_rx_filter_fft512_variants(selection, arrays):
+    """Every instantiation of the N = 512 wave-per-user FFT (k3_lpf_fft512): selected subcarriers 0..K-1 stored from
+    registers (K = 512 unguarded, K = 200 guarded, 512..1023 = the same bins through the stride promise) or any selection
+    through the buffer; packed f16 table for the matrix-core contraction or float table for the vector kernel; Doppler on
+    and off; users with 0, 1 and all paths; delays that are whole samples (np.sinc(0) = 1 taps, channel.py:166-168)."""
+    import deepmimo_amd as dm
+    from oracle import oracle_np as onp
+    N = 512
+    rays = onp.synth_rays(21, 25, seed=512 + len(selection) + len(arrays), max_delay=N / 10e6 * 1.1, with_doppler=True)
+    rays["delay"][3, :6] = (np.arange(6) * 37 / 10e6).astype(rays["delay"].dtype)      # dn = 0, 37, 74, ... samples
+    rays["delay"][4, 0] = 511 / 10e6
+    for k in rays:                                                                       # user 5: one path, user 6: none
+        if rays[k].ndim == 2 and rays[k].shape[1] == 25:
+            rays[k][5, 1:] = np.nan
+            rays[k][6, :] = np.nan
+    sel = {"all512": np.arange(512), "first200": np.arange(200), "offset512": np.arange(512, 1024),
+           "random100": np.sort(np.random.default_rng(7).choice(N, 100, replace=False))}[selection]
+    bs, ue = ([8, 4], [2, 2]) if arrays == "mfma" else ([2, 1], [1, 1])
+    case = dict(bs_shape=bs, ue_shape=ue, bs_spacing=0.5, ue_spacing=0.5, bs_rot=[0, 10, 45],
+                bs_pattern="isotropic", ue_pattern="isotropic", num_paths=25, freq_domain=1, subcarriers=N,
+                selected=list(sel), bandwidth=10e6, rx_filter=1, bs_fov=None, ue_fov=None)
+    ue_rot = np.array([0, 0, 0])
+    op = oracle_params(case, ue_rot)
+    for dop in (0, 1):
+        op["enable_doppler"] = dop
+        ref = onp.compute_channels(rays, op, doppler=dict(vel=rays["doppler_vel"], acc=rays["doppler_acc"], carrier_freq=28e9))
+        ds = dm.Dataset(dict(rays))
+        ds["rt_params"] = {"frequency": 28e9}
+        p = _dm_params(case, ue_rot)
+        p.enable_doppler = dop
+        H = ds.compute_channels(p)
+        assert_channel_close(H, ref["channel"], what=f"lpf512 {selection} {arrays} doppler={dop}")
+
+
 def test_sionna_export_of_time_domain_channels():
     """(a, tau) samples in Sionna's layout (reference: integrations/sionna_adapter.py:174-200) from TD channels."""
     import deepmimo_amd as dm
