@@ -514,7 +514,7 @@ def main():
     if w.get("td"):
         kernel = "k4_td"
     if w.get("lpf"):
-        kernel = "k3_lpf_fft_wave + k2_fd_mfma (table-fed)"
+        kernel = ("k3_lpf_fft512" if w["N"] == 512 else "k3_lpf_fft_wave") + " + k2_fd_mfma (table-fed)"
     split = kernel in ("k2_fd_mfma", "k2_fd_fold", "k2c_beam_power") or bool(w.get("lpf"))
     rows = m_rx * (n_beams if n_beams else m_tx)
     cmacs = n_ue * rows * (1 if w.get("td") else w["N"]) * w["L"]

@@ -51,6 +51,7 @@ struct MfmaArgs {
     const float2* gtab;      // [user_count, P, K] or nullptr
     const uint2* gpack;      // the same table in packed f16 hi/lo form (load_b_step_packed) or nullptr
     int adaptive;            // 1 = a weak last K-step may take one product term (stage_item)
+    int alias_table;         // tuning build only (DMX_LPF_ALIAS_TABLE=1): every user reads user 0's gains - the table out of L2, to price its HBM traffic
 };
 
 // One 32-row tile of one strip: 2*NS ds_read_b128 of A' issued together, 3*NS MFMAs, 16 stores.  NS = K-steps that
@@ -351,14 +352,98 @@ __device__ __forceinline__ void stage_item(const WsView& ws, const MfmaArgs& a, 
     }
 }
 
+// ---- rx_filter path, GSRC = 3: the packed gains of a strip through LDS-DMA ---------------------------------------------
+// On gfx950 loads, stores and LDS-DMA share ONE in-order vmcnt: a wave that loads its next strip's gains (GSRC = 2) waits
+// behind the 128 stores it has just issued.  A load ISSUED IN FRONT of those stores does not wait for them, but 32 more
+// live registers spill ("not kept").  LDS-DMA needs no registers: each wave owns a 4-KiB slot [32 path rows]
+// [16 subcarriers] of packed entries; right after it has read a strip's fragments out of the slot it requests the next
+// strip's (or the next work item's first strip's) entries into it - 4 x `global_load_lds_dwordx4`, lane = (row 8j +
+// lane/8, 16-byte piece lane%8) - and only then starts the tiles and their stores.  At the next strip `s_waitcnt
+// vmcnt(N)` with N = the stores issued since (<= 63) retires the DMA without draining the stores.
+//   * The slots are a static __shared__ array of their own: the compiler then knows that the A' fragment reads (dynamic
+//     LDS) do not alias the DMA's destination and puts no vmcnt wait in front of them.
+//   * The slot itself is read by inline asm (8 x ds_read2_b64 + s_waitcnt lgkmcnt(0) in ONE statement): a visible read
+//     of the DMA's destination would get the compiler's conservative vmcnt wait - the drain this form exists to avoid.
+//     The statement's results pass through ordinary vector instructions (select, rotate) before any MFMA reads them, and
+//     it stands behind the previous strip's 16 stores: nothing of it is near a matrix-core instruction.
+//   * Only for K a multiple of 16 (every strip full, every piece inside its row, 16-byte aligned): other K take GSRC = 2.
+// What it buys, priced with every user reading user 0's rows (tuning build, DMX_LPF_ALIAS_TABLE=1: the table out of
+// L2; headline shape x 100k users, contraction alone = total - 1.86 ms of FFT): register loads 19.4 ms with the table in
+// HBM, 17.4 out of L2; this form 18.8 and 17.1 (the plain kernel, 16 waves: 16.8).  I.e. the queueing was 0.5 ms of the
+// 3.6 the table-fed contraction loses on the plain one; 1.8-2 ms are the 10 GB of table coming out of HBM between the
+// stores, which only a table that never leaves the CU would remove.
+static constexpr int DMA_SLOT_BYTES = 4096;
+
+__device__ __forceinline__ void dma_strip(const uint2* __restrict__ prow, int K, int kidx0, int nrows, unsigned char* slot, int lane) {
+    const int sub = lane >> 3, piece = lane & 7;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 8 * j + sub;
+        if (row < nrows) {
+            const uint2* g = prow + (size_t)row * K + kidx0 + 2 * piece;
+            // aux = 2 (nt): the table is read once - same box, 100k users: 20.72 -> 20.42 ms for FFT + contraction
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(slot + j * 1024), 16, 0, 2);
+        }
+    }
+}
+
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+// fragments of one strip out of the wave's slot: entry (path l, subcarrier c) at l * 128 + c * 8
+__device__ __forceinline__ void read_b_slot(const unsigned char* slot, int col, int hh, int c, int n_act, h8 (&Bhi)[4], h8 (&Blo)[4]) {
+    const uint32_t a0 = (uint32_t)(size_t)(__attribute__((address_space(3))) const void*)slot + (uint32_t)hh * 512u + (uint32_t)(col >> 1) * 8u;
+    const uint32_t a1 = a0 + 2048u;
+    u4v g[8];                                                           // g[2s + (jj >> 1)] = entries jj, jj + 1 of K-step s
+    asm volatile(
+        "ds_read2_b64 %0, %8 offset1:16\n\t"
+        "ds_read2_b64 %1, %8 offset0:32 offset1:48\n\t"
+        "ds_read2_b64 %2, %8 offset0:128 offset1:144\n\t"
+        "ds_read2_b64 %3, %8 offset0:160 offset1:176\n\t"
+        "ds_read2_b64 %4, %9 offset1:16\n\t"
+        "ds_read2_b64 %5, %9 offset0:32 offset1:48\n\t"
+        "ds_read2_b64 %6, %9 offset0:128 offset1:144\n\t"
+        "ds_read2_b64 %7, %9 offset0:160 offset1:176\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7])
+        : "v"(a0), "v"(a1) : "memory");
+    const unsigned rot = c ? 16u : 0u, sgn = c ? 0u : 0x80000000u;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        Bhi[s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+        Blo[s] = Bhi[s];
+        if (8 * s >= n_act) continue;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const bool ok = 8 * s + 4 * hh + jj < n_act;                 // rows from n_act on were not requested: stale bytes
+            const unsigned gx = ok ? g[2 * s + (jj >> 1)][2 * (jj & 1)] : 0u, gy = ok ? g[2 * s + (jj >> 1)][2 * (jj & 1) + 1] : 0u;
+            const unsigned xh = __builtin_amdgcn_alignbit(gx, gx, rot) ^ sgn;
+            const unsigned xl = __builtin_amdgcn_alignbit(gy, gy, rot) ^ sgn;
+            const h2 ph = __builtin_bit_cast(h2, xh), pl2 = __builtin_bit_cast(h2, xl);
+            Bhi[s][2 * jj] = ph[0]; Bhi[s][2 * jj + 1] = ph[1];
+            Blo[s][2 * jj] = pl2[0]; Blo[s][2 * jj + 1] = pl2[1];
+        }
+    }
+}
+
+// retire the DMA that was issued in front of the last `ntiles` x 16 stores of this wave (in-order vmcnt; at most 63 countable)
+__device__ __forceinline__ void wait_dma_behind_stores(int ntiles) {
+    if (ntiles >= 4) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+    else if (ntiles == 3) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+    else if (ntiles == 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else if (ntiles == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // Stage 2 of a work item, after a barrier behind stage_item: a wave owns one 32-column strip at a time (B'
 // fragments in registers) and walks the row tiles with it, so the waves of the workgroup fill one 32-row band of the
 // user's block together and their stores stay within a few DRAM pages.  No barrier inside.
 // GSRC: where the subcarrier gains G[l,k] come from - 0 generated here (plain path), 1 float table, 2 packed f16 table
 // (rx_filter path).  A template parameter: the plain kernel carries none of the table code.
+// GSRC = 3: `prefetched` says that this wave's slot already holds (or is receiving) the item's first strip; the return
+// value says the same for the next item.
 template <bool NT, int NW, int MODE, int GSRC>
-__device__ __forceinline__ void consume_item(const WsView& ws, const MfmaArgs& a, float* __restrict__ out, int64_t work,
-                                             int64_t next_work, const ItemLds& L) {
+__device__ __forceinline__ bool consume_item(const WsView& ws, const MfmaArgs& a, float* __restrict__ out, int64_t work,
+                                             int64_t next_work, const ItemLds& L, bool prefetched) {
     constexpr int NTHR = NW * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const ItemPos ip = item_pos(ws, a, work);
@@ -368,13 +453,15 @@ __device__ __forceinline__ void consume_item(const WsView& ws, const MfmaArgs& a
     if (n_act == 0) {                                                    // channel.py:270-271
         const size_t nel = (size_t)ip.nrows * twoK;
         for (size_t i = tid; i < nel; i += NTHR) o[i] = 0.f;
-        return;
+        return false;
     }
     const float oscale = L.misc[0];
     const float gscale = L.misc[2];
     const bool last_weak = L.misc[3] != 0.f;                             // workgroup-uniform
     const float2* grow = GSRC == 1 ? a.gtab + (size_t)ip.ul * ws.P * a.K : nullptr;
-    const uint2* prow = GSRC == 2 ? a.gpack + (size_t)ip.ul * ws.P * a.K : nullptr;
+    const int64_t tul = a.alias_table ? 0 : ip.ul;                       // user whose rows of the gains table are read
+    const uint2* prow = GSRC == 2 ? a.gpack + (size_t)tul * ws.P * a.K : nullptr;
+    (void)prefetched;
 
     const int col = lane & 31, hh = lane >> 5;
     const unsigned row_bytes = (unsigned)twoK * 4u;
@@ -382,13 +469,44 @@ __device__ __forceinline__ void consume_item(const WsView& ws, const MfmaArgs& a
     const int nstrips = (int)((twoK + 31) >> 5);
     const int ntiles = (ip.nrows + 31) >> 5;
     unsigned touched = 0;
+    bool next_prefetched = false;
+    unsigned char* slot = nullptr;
+    int nn_next = 0;
+    if constexpr (GSRC == 3) {
+        __shared__ __attribute__((aligned(16))) unsigned char dma_slots[NW * DMA_SLOT_BYTES];
+        slot = dma_slots + wave * DMA_SLOT_BYTES;
+        // path count of the next item's user, fetched HERE (behind the barrier, nothing in flight): a load result first
+        // used between the strips' stores would make the compiler drain them
+        if (next_work >= 0) {
+            const int nn = __builtin_amdgcn_readfirstlane(ws.n_keep[a.user_begin + next_work / a.nblk]);
+            nn_next = nn < LPAD ? nn : LPAD;
+        }
+        if (wave < nstrips) {
+            if (!prefetched) dma_strip(a.gpack + (size_t)tul * ws.P * a.K, a.K, wave * 16, n_act, slot, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // behind the item's barrier nothing else is in flight
+        }
+    }
     for (int strip = wave; strip < nstrips; strip += NW) {
         const BLane bl = b_lane(strip, col, hh, twoK, a.sc);
         h8 Bhi[4], Blo[4];
+        if constexpr (GSRC == 3) {
+            const uint2* urow = a.gpack + (size_t)tul * ws.P * a.K;
+            if (strip != wave) wait_dma_behind_stores(ntiles);
+            read_b_slot(slot, col, hh, bl.c, n_act, Bhi, Blo);
+            const int ns = strip + NW;
+            if (ns < nstrips) {
+                dma_strip(urow, a.K, ns * 16, n_act, slot, lane);
+            } else if (next_work >= 0) {                                 // the next item's first strip of this wave
+                const int64_t nul = a.alias_table ? 0 : next_work / a.nblk;
+                dma_strip(a.gpack + (size_t)nul * ws.P * a.K, a.K, wave * 16, nn_next, slot, lane);
+                next_prefetched = true;
+            }
+        } else {
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            if constexpr (GSRC == 2) load_b_step_packed(st, bl, hh, n_act, prow, a.K, Bhi[st], Blo[st]);
-            else gen_b_step(ws.neg_one, st, bl, hh, n_act, L.qtab, L.crtab, L.citab, grow, a.K, gscale, Bhi[st], Blo[st]);
+            for (int st = 0; st < 4; ++st) {
+                if constexpr (GSRC == 2) load_b_step_packed(st, bl, hh, n_act, prow, a.K, Bhi[st], Blo[st]);
+                else gen_b_step(ws.neg_one, st, bl, hh, n_act, L.qtab, L.crtab, L.citab, grow, a.K, gscale, Bhi[st], Blo[st]);
+            }
         }
         if constexpr (GSRC == 2) {
             // The table reads are cold HBM misses in front of a dependent MFMA chain (with every user aliased to one
@@ -422,6 +540,7 @@ __device__ __forceinline__ void consume_item(const WsView& ws, const MfmaArgs& a
                 mfma_tile_rt<NT>(pt, L.Ahi, L.Alo, col, hh, n_act, n_full, Bhi, Blo, bl, orsrc, row_bytes, oscale);
         }
     }
+    return next_prefetched;
 }
 
 // One (user, row block) per loop iteration.  Launched with one workgroup per work item, or persistently (grid =
@@ -430,10 +549,11 @@ template <bool NT, int NW, int MODE, int GSRC>
 __global__ __launch_bounds__(NW * 64, 4) void k2_fd_mfma(WsView ws, MfmaArgs a, float* __restrict__ out, int64_t total) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ItemLds L = item_lds(smem, a.rows);
+    bool prefetched = false;                                             // GSRC = 3, per wave: see consume_item
     for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
         stage_item<NW>(ws, a, w, L);
         __syncthreads();
-        consume_item<NT, NW, MODE, GSRC>(ws, a, out, w, (w + gridDim.x < total) ? w + gridDim.x : (int64_t)-1, L);
+        prefetched = consume_item<NT, NW, MODE, GSRC>(ws, a, out, w, (w + gridDim.x < total) ? w + gridDim.x : (int64_t)-1, L, prefetched);
         __syncthreads();                                                 // the next item's tiles overwrite these
     }
 }
@@ -747,6 +867,7 @@ static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user
     MfmaArgs a;
     a.n_beams = n_beams; a.ftab = ftab; a.fexp = fexp; a.gtab = gtab; a.gpack = gpack;
     a.adaptive = !n_beams && !gtab && !gpack && (prm.flags & DMX_FLAG_ADAPTIVE_TERMS);   // default: three product terms everywhere
+    a.alias_table = tuning_int("DMX_LPF_ALIAS_TABLE", 0);
     a.user_begin = user_begin;
     a.m_rx = prm.ue_shape[0] * prm.ue_shape[1];
     a.m_tx = prm.bs_shape[0] * prm.bs_shape[1];
@@ -757,6 +878,12 @@ static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user
     a.sc = prm.selected_subcarriers;
     a.inv_n = 1.0 / (double)prm.n_subcarriers;
     const int nstrips = (2 * a.K + 31) / 32;
+    // rx_filter with the packed table, every strip full and whole 256-row blocks: gains through LDS-DMA (GSRC = 3) in ONE
+    // 16-wave workgroup per CU (A' tiles 73.7 KB + 16 slots 64 KB).  Same box, headline shape x 100k users, FFT +
+    // contraction: register loads (GSRC = 2, two 8-wave workgroups) 21.2 ms, this 20.7, with nt DMA and nt table stores
+    // 20.2-20.3; 8 waves x 128-row blocks (two workgroups per CU, the fragments read twice per user) 21.5.
+    // tuning build only: DMX_LPF_DMA=0 takes the register loads
+    const int dma = (gpack && a.K % 16 == 0 && a.M >= MAX_ROWS && nstrips >= 16) ? tuning_int("DMX_LPF_DMA", 1) : 0;
     a.nblk = (a.M + MAX_ROWS - 1) / MAX_ROWS;
     const int mrows = a.M < MAX_ROWS ? a.M : MAX_ROWS;
     a.rows = (mrows + 31) / 32 * 32;
@@ -782,7 +909,7 @@ static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user
     // 16-wave workgroup then fills a CU alone, while two 8-wave workgroups share it and overlap each other's phases:
     // 16.0 vs 16.8 ms at the headline shape, 31.7 vs 32.5 at config 5, 8.3 vs 8.8 at config 2 x 200k users.
     auto go8 = [&](bool persistent, int items_per_wg) {
-        if (a.rows < 128) return launch_mfma_t<true, 8, 0>(ws, a, blocks, smem, out, stream, persistent, items_per_wg);
+        if (a.rows < 128 || tuning_int("DMX_PLAIN_TILE_MODE", 2) == 0) return launch_mfma_t<true, 8, 0>(ws, a, blocks, smem, out, stream, persistent, items_per_wg);
         if (ws.P <= 16) return launch_mfma_t<true, 8, 1>(ws, a, blocks, smem, out, stream, persistent, items_per_wg);
         return launch_mfma_t<true, 8, 2>(ws, a, blocks, smem, out, stream, persistent, items_per_wg);
     };
@@ -792,6 +919,7 @@ static int launch_mfma_any(const dmx_params& prm, const WsView& ws, int64_t user
             // with the fragments coming out of loads the register-lean tile loop wins at every row count: headline shape
             // x 20k users, stage 2 in all: MODE 0 5.43 ms, MODE 1 5.85, MODE 2 (pipelined, 116 B/lane of scratch) 5.61
             const int m1 = tuning_int("DMX_LPF_TILE_MODE", 0);        // tuning build only: 1 / 2 = the grouped / pipelined bodies
+            if (dma == 1) return launch_mfma_t<true, 16, 0, 3>(ws, a, blocks, smem, out, stream, true, ITEMS_PER_WG);
             if (small) return launch_mfma_t<true, 4, 0, 2>(ws, a, blocks, smem, out, stream, true, 0);
             if (a.rows >= 128 && m1 == 1) return launch_mfma_t<true, 8, 1, 2>(ws, a, blocks, smem, out, stream, true, ITEMS_PER_WG8);
             if (a.rows >= 128 && m1 == 2) return launch_mfma_t<true, 8, 2, 2>(ws, a, blocks, smem, out, stream, true, ITEMS_PER_WG8);

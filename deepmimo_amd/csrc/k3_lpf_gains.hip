@@ -405,7 +405,9 @@ __device__ __forceinline__ void store_gain(float2* grow, uint2* prow, int k, flo
     if constexpr (PACK) {
         h2 hi, lo;
         split2_f16(g.x, g.y, hi, lo, m1);
-        prow[k] = make_uint2(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo));
+        typedef unsigned u2v __attribute__((ext_vector_type(2)));
+        const u2v w = {__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo)};
+        __builtin_nontemporal_store(w, reinterpret_cast<u2v*>(prow + k));     // read back once, by another CU
     } else {
         grow[k] = g;
     }

@@ -608,13 +608,16 @@ def test_rx_filter_fft_and_mfma_path(N, K):
         assert_channel_close(H, ref["channel"], what=f"lpf N={N} K={K} doppler={dop}")
 
 
-@pytest.mark.parametrize("arrays", ["mfma", "valu"])
-@pytest.mark.parametrize("selection", ["all512", "first200", "random100", "offset512"])
+@pytest.mark.parametrize("arrays", ["mfma", "valu", "dma256", "dma320"])
+@pytest.mark.parametrize("selection", ["all512", "first200", "random100", "offset512", "even256"])
 def test_rx_filter_fft512_variants(selection, arrays):
     """Every instantiation of the N = 512 wave-per-user FFT (k3_lpf_fft512): selected subcarriers 0..K-1 stored from
     registers (K = 512 unguarded, K = 200 guarded, 512..1023 = the same bins through the stride promise) or any selection
     through the buffer; packed f16 table for the matrix-core contraction or float table for the vector kernel; Doppler on
-    and off; users with 0, 1 and all paths; delays that are whole samples (np.sinc(0) = 1 taps, channel.py:166-168)."""
+    and off; users with 0, 1 and all paths; delays that are whole samples (np.sinc(0) = 1 taps, channel.py:166-168).
+    dma256 / dma320: 256 and 320 antenna pairs with K a multiple of 16 take the LDS-DMA form of the contraction
+    (k2_fd_mfma<.., GSRC = 3>): whole and ragged row blocks (8 and 2 tiles per strip: both counted waits), the prefetch
+    chain across work items broken by the user without paths."""
     import deepmimo_amd as dm
     from oracle import oracle_np as onp
     N = 512
@@ -626,8 +629,9 @@ def test_rx_filter_fft512_variants(selection, arrays):
             rays[k][5, 1:] = np.nan
             rays[k][6, :] = np.nan
     sel = {"all512": np.arange(512), "first200": np.arange(200), "offset512": np.arange(512, 1024),
+           "even256": np.arange(0, 512, 2),
            "random100": np.sort(np.random.default_rng(7).choice(N, 100, replace=False))}[selection]
-    bs, ue = ([8, 4], [2, 2]) if arrays == "mfma" else ([2, 1], [1, 1])
+    bs, ue = {"mfma": ([8, 4], [2, 2]), "valu": ([2, 1], [1, 1]), "dma256": ([8, 8], [2, 2]), "dma320": ([10, 8], [2, 2])}[arrays]
     case = dict(bs_shape=bs, ue_shape=ue, bs_spacing=0.5, ue_spacing=0.5, bs_rot=[0, 10, 45],
                 bs_pattern="isotropic", ue_pattern="isotropic", num_paths=25, freq_domain=1, subcarriers=N,
                 selected=list(sel), bandwidth=10e6, rx_filter=1, bs_fov=None, ue_fov=None)

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--workload", default="c3_headline")
     ap.add_argument("--quick", action="store_true", help="skip the plain path and the round-1 FFT")
+    ap.add_argument("--plain-only", action="store_true", help="the plain path alone")
     args = ap.parse_args()
     w = dict(bench.WORKLOADS[args.workload])
     w["n_ue"] = args.users
@@ -34,7 +35,7 @@ def main():
     res = {}
     cases = (("plain (rx_filter = 0)", 0, "0"), ("rx_filter = 1, wave-per-path radix-8 FFT", 1, "0"),
              ("rx_filter = 1, workgroup-per-user radix-2 FFT (round 1)", 1, "1"))
-    for label, lpf, old in (cases[1:2] if args.quick else cases):
+    for label, lpf, old in (cases[:1] if args.plain_only else cases[1:2] if args.quick else cases):
         os.environ["DMX_LPF_OLD_FFT"] = old
         p = bench.make_params(w)
         p.ofdm.rx_filter = lpf
