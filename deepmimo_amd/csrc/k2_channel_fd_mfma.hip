@@ -393,34 +393,34 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void read_b_slot(const unsigned char* slot, int col, int hh, int c, int n_act, h8 (&Bhi)[4], h8 (&Blo)[4]) {
     const uint32_t a0 = (uint32_t)(size_t)(__attribute__((address_space(3))) const void*)slot + (uint32_t)hh * 512u + (uint32_t)(col >> 1) * 8u;
     const uint32_t a1 = a0 + 2048u;
-    u4v g[8];                                                           // g[2s + (jj >> 1)] = entries jj, jj + 1 of K-step s
-    asm volatile(
-        "ds_read2_b64 %0, %8 offset1:16\n\t"
-        "ds_read2_b64 %1, %8 offset0:32 offset1:48\n\t"
-        "ds_read2_b64 %2, %8 offset0:128 offset1:144\n\t"
-        "ds_read2_b64 %3, %8 offset0:160 offset1:176\n\t"
-        "ds_read2_b64 %4, %9 offset1:16\n\t"
-        "ds_read2_b64 %5, %9 offset0:32 offset1:48\n\t"
-        "ds_read2_b64 %6, %9 offset0:128 offset1:144\n\t"
-        "ds_read2_b64 %7, %9 offset0:160 offset1:176\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7])
-        : "v"(a0), "v"(a1) : "memory");
     const unsigned rot = c ? 16u : 0u, sgn = c ? 0u : 0x80000000u;
+    // two K-steps per statement: 16 transient registers instead of 32
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        Bhi[s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
-        Blo[s] = Bhi[s];
-        if (8 * s >= n_act) continue;
+    for (int half = 0; half < 2; ++half) {
+        u4v g[4];                                                       // g[2 (s & 1) + (jj >> 1)] = entries jj, jj + 1 of K-step s
+        asm volatile(
+            "ds_read2_b64 %0, %4 offset1:16\n\t"
+            "ds_read2_b64 %1, %4 offset0:32 offset1:48\n\t"
+            "ds_read2_b64 %2, %4 offset0:128 offset1:144\n\t"
+            "ds_read2_b64 %3, %4 offset0:160 offset1:176\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]) : "v"(half ? a1 : a0) : "memory");
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const bool ok = 8 * s + 4 * hh + jj < n_act;                 // rows from n_act on were not requested: stale bytes
-            const unsigned gx = ok ? g[2 * s + (jj >> 1)][2 * (jj & 1)] : 0u, gy = ok ? g[2 * s + (jj >> 1)][2 * (jj & 1) + 1] : 0u;
-            const unsigned xh = __builtin_amdgcn_alignbit(gx, gx, rot) ^ sgn;
-            const unsigned xl = __builtin_amdgcn_alignbit(gy, gy, rot) ^ sgn;
-            const h2 ph = __builtin_bit_cast(h2, xh), pl2 = __builtin_bit_cast(h2, xl);
-            Bhi[s][2 * jj] = ph[0]; Bhi[s][2 * jj + 1] = ph[1];
-            Blo[s][2 * jj] = pl2[0]; Blo[s][2 * jj + 1] = pl2[1];
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int s = 2 * half + s2;
+            Bhi[s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+            Blo[s] = Bhi[s];
+            if (8 * s >= n_act) continue;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const bool ok = 8 * s + 4 * hh + jj < n_act;             // rows from n_act on were not requested: stale bytes
+                const unsigned gx = ok ? g[2 * s2 + (jj >> 1)][2 * (jj & 1)] : 0u, gy = ok ? g[2 * s2 + (jj >> 1)][2 * (jj & 1) + 1] : 0u;
+                const unsigned xh = __builtin_amdgcn_alignbit(gx, gx, rot) ^ sgn;
+                const unsigned xl = __builtin_amdgcn_alignbit(gy, gy, rot) ^ sgn;
+                const h2 ph = __builtin_bit_cast(h2, xh), pl2 = __builtin_bit_cast(h2, xl);
+                Bhi[s][2 * jj] = ph[0]; Bhi[s][2 * jj + 1] = ph[1];
+                Blo[s][2 * jj] = pl2[0]; Blo[s][2 * jj + 1] = pl2[1];
+            }
         }
     }
 }

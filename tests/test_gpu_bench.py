@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CASES = [("c3_headline", 300, "k2_fd_mfma", "hbm"), ("c5_massive", 12, "k2_fd_mfma", "hbm"), ("d8_default_arrays", 2000, "k2_fd_fold", "hbm"),
          ("d64_k256", 500, "k2_fd_fold", "hbm"), ("c3_beam_power", 300, "k2c_beam_power", "mfma"),
-         ("c3_time_domain", 500, "k4_td", "hbm"), ("c3_rx_filter", 200, "k3_lpf_fft_wave + k2_fd_mfma (table-fed)", "hbm")]
+         ("c3_time_domain", 500, "k4_td", "hbm"), ("c3_rx_filter", 200, "k3_lpf_fft512 + k2_fd_mfma (table-fed)", "hbm")]
 
 
 @pytest.mark.parametrize("workload,users,kernel,bound", CASES, ids=[c[0] for c in CASES])
