@@ -16,7 +16,7 @@ FLAG_ADAPTIVE_TERMS = 1
 
 EXPORTED_SYMBOLS = ("dmx_version", "dmx_last_error", "dmx_workspace_bytes", "dmx_decode_max_delay",
                     "dmx_path_prep", "dmx_channels_fd", "dmx_channels_td", "dmx_channels_fd_lpf",
-                    "dmx_lpf_workspace_bytes", "dmx_mat5_find", "dmx_mat_to_rowmajor_f32",
+                    "dmx_lpf_workspace_bytes", "dmx_mat5_find", "dmx_mat_to_rowmajor_f32", "dmx_mats_to_device",
                     "dmx_beam_workspace_bytes", "dmx_channels_fd_beams", "dmx_pathloss",
                     "dmx_p2m_count_rx", "dmx_p2m_parse_paths", "dmx_fd_kernel_choice", "dmx_beam_power")
 
@@ -61,6 +61,12 @@ class DmxMatInfo(C.Structure):
     _fields_ = [("class_id", C.c_int32), ("data_type", C.c_int32), ("elem_bytes", C.c_int32), ("ndim", C.c_int32),
                 ("dims", C.c_int64 * 4), ("data_offset", C.c_int64), ("data_bytes", C.c_int64),
                 ("compressed", C.c_int32), ("reserved", C.c_int32), ("comp_offset", C.c_int64), ("comp_bytes", C.c_int64)]
+
+
+class DmxMatJob(C.Structure):
+    _fields_ = [("path", C.c_char_p), ("file_offset", C.c_uint64), ("nbytes", C.c_uint64), ("stage_offset", C.c_uint64),
+                ("d_payload", C.c_void_p), ("data_type", C.c_int32), ("cols_keep", C.c_int32),
+                ("rows", C.c_int64), ("cols", C.c_int64), ("d_out", C.c_void_p)]
 
 
 class NativeError(RuntimeError):
@@ -122,6 +128,8 @@ def load():
     lib.dmx_mat_to_rowmajor_f32.restype = C.c_int
     lib.dmx_mat_to_rowmajor_f32.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
                                             C.c_int32, C.c_void_p, C.c_void_p]
+    lib.dmx_mats_to_device.restype = C.c_int
+    lib.dmx_mats_to_device.argtypes = [C.POINTER(DmxMatJob), C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
     v = lib.dmx_version()
     if v != ABI_VERSION:
         raise RuntimeError(f"deepmimo_amd: ABI mismatch, library reports {v}, binding expects {ABI_VERSION}")

@@ -152,6 +152,7 @@ def _load_tx_rx_raydata(folder: str, tx_set_id: int, rx_set_id: int, tx_idx: int
         if bad:
             raise ValueError(f"Invalid matrix names: {bad}. Valid names are: {set(_MATRIX_KEYS)}")
     d: Dict[str, Any] = {k: None for k in _MATRIX_KEYS}
+    on_device = []
     for key in _MATRIX_KEYS:
         if key not in wanted:
             continue
@@ -160,8 +161,7 @@ def _load_tx_rx_raydata(folder: str, tx_set_id: int, rx_set_id: int, tx_idx: int
             print(f"File {path} could not be found")
             continue
         if device is not None and key in c.RAY_FIELDS:
-            from .matio import load_matrix_to_device
-            d[key] = load_matrix_to_device(path, key, device, rx_idxs=rx_idxs, max_paths=max_paths)
+            on_device.append((path, key))                       # all ray matrices of the pair in one pipeline, below
             continue
         m = scipy.io.loadmat(path)[key]
         if key != c.TX_POS_PARAM_NAME:
@@ -169,4 +169,7 @@ def _load_tx_rx_raydata(folder: str, tx_set_id: int, rx_set_id: int, tx_idx: int
         if key not in (c.RX_POS_PARAM_NAME, c.TX_POS_PARAM_NAME):
             m = m[:, :max_paths, ...]
         d[key] = m
+    if on_device:
+        from .matio import load_matrices_to_device
+        d.update(load_matrices_to_device(on_device, device, rx_idxs=rx_idxs, max_paths=max_paths))
     return d

@@ -12,6 +12,11 @@
 // layout) and the writes (along a row of the output) are coalesced.
 #include "dmx_common.h"
 #include <string.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <atomic>
+#include <thread>
+#include <vector>
 
 namespace dmx {
 
@@ -93,6 +98,76 @@ int dmx_mat_to_rowmajor_f32(const void* d_payload, int32_t data_type, int64_t ro
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("k_mat_to_rowmajor launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
     return DMX_OK;
+}
+
+// include/deepmimo_amd.h: dmx_mats_to_device.  Tasks are (job, slice) in job-major order behind one atomic counter, so
+// the jobs complete in order, the first after 1 / n_jobs of the whole read time; the calling thread issues the copy and
+// the layout kernel of a job the moment its last slice has landed.
+int dmx_mats_to_device(const dmx_mat_job* jobs, int32_t n_jobs, void* staging, const int64_t* d_row_idx, int64_t n_sel,
+                       int32_t n_threads, void* stream) {
+    if (n_jobs < 0 || (n_jobs > 0 && (!jobs || !staging))) { set_error("jobs / staging is NULL"); return DMX_ERR_ARG; }
+    if (n_jobs == 0) return DMX_OK;
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 32) n_threads = 32;
+    struct Task { int job; uint64_t lo, hi; };
+    std::vector<Task> tasks;
+    std::vector<int> fds((size_t)n_jobs, -1);
+    std::vector<std::atomic<int>> remaining((size_t)n_jobs);
+    for (int j = 0; j < n_jobs; ++j) {
+        int cnt = 0;
+        if (jobs[j].path && jobs[j].nbytes) {
+            fds[j] = open(jobs[j].path, O_RDONLY);
+            if (fds[j] < 0) {
+                for (int k = 0; k < j; ++k) if (fds[k] >= 0) close(fds[k]);
+                set_error("cannot open %s", jobs[j].path);
+                return DMX_ERR_ARG;
+            }
+            uint64_t step = (jobs[j].nbytes + (uint64_t)n_threads - 1) / (uint64_t)n_threads;
+            step = (step + 4095) & ~(uint64_t)4095;
+            if (step < 65536) step = 65536;
+            for (uint64_t lo = 0; lo < jobs[j].nbytes; lo += step, ++cnt)
+                tasks.push_back({j, lo, lo + step < jobs[j].nbytes ? lo + step : jobs[j].nbytes});
+        }
+        remaining[j].store(cnt);
+    }
+    std::atomic<size_t> next(0);
+    std::atomic<int> failed(0);
+    auto worker = [&]() {
+        for (;;) {
+            const size_t t = next.fetch_add(1);
+            if (t >= tasks.size()) return;
+            const Task& tk = tasks[t];
+            const dmx_mat_job& jb = jobs[tk.job];
+            char* dst = static_cast<char*>(staging) + jb.stage_offset;
+            uint64_t got = tk.lo;
+            while (got < tk.hi && !failed.load(std::memory_order_relaxed)) {
+                const ssize_t n = pread(fds[tk.job], dst + got, (size_t)(tk.hi - got), (off_t)(jb.file_offset + got));
+                if (n <= 0) { failed.store(1); break; }
+                got += (uint64_t)n;
+            }
+            remaining[tk.job].fetch_sub(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> pool;
+    const int nthr = (int)tasks.size() < n_threads ? (int)tasks.size() : n_threads;
+    for (int i = 0; i < nthr; ++i) pool.emplace_back(worker);
+    int rc = DMX_OK;
+    for (int j = 0; j < n_jobs && rc == DMX_OK; ++j) {
+        while (remaining[j].load(std::memory_order_acquire) > 0) std::this_thread::yield();
+        if (failed.load()) { set_error("short read of %s", jobs[j].path ? jobs[j].path : "(staged)"); rc = DMX_ERR_ARG; break; }
+        const dmx_mat_job& jb = jobs[j];
+        if (jb.nbytes) {
+            hipError_t e = hipMemcpyAsync(jb.d_payload, static_cast<char*>(staging) + jb.stage_offset, (size_t)jb.nbytes,
+                                          hipMemcpyHostToDevice, (hipStream_t)stream);
+            if (e != hipSuccess) { set_error("hipMemcpyAsync failed: %s", hipGetErrorString(e)); rc = DMX_ERR_LAUNCH; break; }
+        }
+        rc = dmx_mat_to_rowmajor_f32(jb.d_payload, jb.data_type, jb.rows, jb.cols, d_row_idx, d_row_idx ? n_sel : jb.rows,
+                                     jb.cols_keep, jb.d_out, stream);
+    }
+    if (rc != DMX_OK) failed.store(1);
+    for (auto& t : pool) t.join();
+    for (int fd : fds) if (fd >= 0) close(fd);
+    return rc;
 }
 
 }  // extern "C"

@@ -238,6 +238,26 @@ int dmx_mat5_find(const void* file_image, size_t len, const char* var_name, dmx_
 int dmx_mat_to_rowmajor_f32(const void* d_payload, int32_t data_type, int64_t rows, int64_t cols,
                             const int64_t* d_row_idx, int64_t n_sel, int32_t cols_keep, float* d_out, void* stream);
 
+/* All ray matrices of a TX/RX pair in one pipeline (core.py:241-254 loads them one `scipy.io.loadmat` at a time): reader
+ * threads of the library `pread` the payloads - every file in slices by all threads, file after file - into `staging`
+ * (host memory the caller page-locked, e.g. hipHostMalloc; job i's bytes at stage_offset), while the calling thread, as
+ * each file completes, queues its asynchronous H2D copy into d_payload and dmx_mat_to_rowmajor_f32 on `stream`.  Returns
+ * when everything is QUEUED: `staging`, every d_payload and d_row_idx must stay untouched until the stream has been
+ * synchronised.  path == NULL: the job's bytes are in `staging` already (an inflated miCOMPRESSED element). */
+typedef struct dmx_mat_job {
+    const char* path;        /* file holding the payload, or NULL */
+    uint64_t file_offset;    /* dmx_mat_info.data_offset */
+    uint64_t nbytes;         /* dmx_mat_info.data_bytes */
+    uint64_t stage_offset;   /* where the payload goes inside `staging` */
+    void*    d_payload;      /* device, nbytes */
+    int32_t  data_type;      /* dmx_mat_info.data_type */
+    int32_t  cols_keep;
+    int64_t  rows, cols;
+    float*   d_out;          /* device float32 [n_sel, cols_keep] */
+} dmx_mat_job;
+int dmx_mats_to_device(const dmx_mat_job* jobs, int32_t n_jobs, void* staging, const int64_t* d_row_idx, int64_t n_sel,
+                       int32_t n_threads, void* stream);
+
 /* ---- two steps before the path: Wireless InSite paths.p2m text -> ray matrices ----- */
 
 /* Receiver count announced on line 22 of a `*.paths.*.p2m` file image (p2m_parser.py:36, 80); -1 on error. */
