@@ -16,10 +16,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def k2_value(path, counter, kernel="dmx::k2_fd"):
-    for r in csv.DictReader(open(path)):
-        if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
-            return float(r["Counter_Value"])
-    raise SystemExit(f"{counter} of the stage-2 kernel not found in {path}")
+    """`kernel`: substring of the kernel's name; several, comma-separated, are summed (rx_filter: FFT + contraction)."""
+    total, found = 0.0, 0
+    for sub in kernel.split(","):
+        for r in csv.DictReader(open(path)):
+            if sub in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                total += float(r["Counter_Value"])
+                found += 1
+                break
+    if found != len(kernel.split(",")):
+        raise SystemExit(f"{counter} of the stage-2 kernel(s) '{kernel}' not found in {path}")
+    return total
 
 
 def main():
@@ -34,7 +41,8 @@ def main():
     import glob
     for g in glob.glob(os.path.join(os.path.dirname(os.path.dirname(wcsv)).replace("_pmc_WRITE_SIZE", "_pmc_GRBM*"), "*", "*counter_collection.csv")):
         try:
-            mfma_busy = k2_value(g, "SQ_VALU_MFMA_BUSY_CYCLES", kernel) / (k2_value(g, "GRBM_GUI_ACTIVE", kernel) / 8 * 1024)
+            k0 = kernel.split(",")[0]
+            mfma_busy = k2_value(g, "SQ_VALU_MFMA_BUSY_CYCLES", k0) / (k2_value(g, "GRBM_GUI_ACTIVE", k0) / 8 * 1024)
         except SystemExit:
             pass
     out = os.path.join(ROOT, "profiles", "traffic.json")
