@@ -182,6 +182,56 @@ template <> __device__ __forceinline__ void dft_small<8>(float2 (&v)[8]) {
     for (int m = 0; m < 4; ++m) { v[2 * m] = a[m]; v[2 * m + 1] = b[m]; }
 }
 
+// Packed-fp32 forms the compiler does not select (it keeps a swizzled copy of every twiddle - 56 registers instead of 28 -
+// negates with v_xor and moves halves around for the multiplications by -j: 3 instructions per complex product, 37 per
+// radix-8 butterfly).  op_sel / op_sel_hi pick the 32-bit half that feeds the low / high result, neg_lo / neg_hi negate it.
+// None of these reads a transcendental's result directly (taps and Doppler phasors go through compiler-selected
+// multiplies first), and there are no matrix-core instructions in this file.
+__device__ __forceinline__ float2 cmul_pk(float2 a, float2 b) {              // a * b: 2 instructions, b as it is
+    kv2 r;
+    const kv2 av = {a.x, a.y}, bv = {b.x, b.y};
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=&v"(r) : "v"(av), "v"(bv));
+    return make_float2(r[0], r[1]);
+}
+__device__ __forceinline__ float2 cadd_mj(float2 a, float2 b) {              // a + (-j) b = (a.x + b.y, a.y - b.x)
+    kv2 r;
+    const kv2 av = {a.x, a.y}, bv = {b.x, b.y};
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(av), "v"(bv));
+    return make_float2(r[0], r[1]);
+}
+__device__ __forceinline__ float2 csub_mj(float2 a, float2 b) {              // a - (-j) b = (a.x - b.y, a.y + b.x)
+    kv2 r;
+    const kv2 av = {a.x, a.y}, bv = {b.x, b.y};
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(av), "v"(bv));
+    return make_float2(r[0], r[1]);
+}
+__device__ __forceinline__ float2 rot1_pk(float2 b) {                        // sqrt(2) e^{-j pi/4} b = (x + y, y - x)
+    kv2 r;
+    const kv2 bv = {b.x, b.y};
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(bv));
+    return make_float2(r[0], r[1]);
+}
+__device__ __forceinline__ float2 rot3_pk(float2 b) {                        // sqrt(2) e^{-j 3pi/4} b = (y - x, -x - y)
+    kv2 r;
+    const kv2 bv = {b.x, b.y};
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[1,0] neg_hi:[1,1]" : "=v"(r) : "v"(bv));
+    return make_float2(r[0], r[1]);
+}
+__device__ __forceinline__ float2 cscale(float2 a, float s) { const kv2 r = kv2{a.x, a.y} * s; return make_float2(r[0], r[1]); }
+// radix-8 butterfly, 28 packed instructions (dft_small<8> with the -j factors folded into the additions)
+__device__ __forceinline__ void dft8_pk(float2 (&v)[8]) {
+    constexpr float H = 0.70710678118654752f;
+    float2 a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a[k] = caddf(v[k], v[k + 4]); b[k] = csubf(v[k], v[k + 4]); }
+    const float2 b1 = cscale(rot1_pk(b[1]), H), b3 = cscale(rot3_pk(b[3]), H);
+    const float2 t0 = caddf(a[0], a[2]), t1 = csubf(a[0], a[2]), t2 = caddf(a[1], a[3]), d = csubf(a[1], a[3]);
+    v[0] = caddf(t0, t2); v[2] = cadd_mj(t1, d); v[4] = csubf(t0, t2); v[6] = csub_mj(t1, d);
+    const float2 u0 = cadd_mj(b[0], b[2]), u1 = csub_mj(b[0], b[2]), u2 = caddf(b1, b3), e = csubf(b1, b3);
+    v[1] = caddf(u0, u2); v[3] = cadd_mj(u1, e); v[5] = csubf(u0, u2); v[7] = csub_mj(u1, e);
+}
+
 // element e of a transform buffer lives at e + e/16: the pad makes the stride-8 writes of the first pass (lane l writes
 // elements 8l + r: two banks for the whole wave without it) conflict-free and costs the other passes at most 2-way
 __device__ __forceinline__ int fpad(int e) { return e + (e >> 4); }
@@ -199,9 +249,10 @@ __device__ __forceinline__ void fft_pass(const float2* src, float2* dst, const f
         for (int r = 0; r < R; ++r) v[r] = src[fpad(j + r * nb)];
         if (Ns > 1) {
 #pragma unroll
-            for (int r = 1; r < R; ++r) v[r] = cmulf(v[r], W[(k * r) << tw_shift]);
+            for (int r = 1; r < R; ++r) v[r] = cmul_pk(v[r], W[(k * r) << tw_shift]);
         }
-        dft_small<R>(v);
+        if constexpr (R == 8) dft8_pk(v);
+        else dft_small<R>(v);
         const int j0 = ((j - k) << LR) + k;
 #pragma unroll
         for (int r = 0; r < R; ++r) dst[fpad(j0 + r * Ns)] = v[r];
@@ -350,56 +401,6 @@ __global__ __launch_bounds__(256, K3_WAVES_PER_SIMD) void k3_lpf_fft_wave(WsView
 //     with one per-lane S per path, i.e. subtract, reciprocal, one packed multiply per tap;
 //   * a wave owns a USER (all its paths in turn): no workgroup barrier, no 7 / 6 / 6 / 6 imbalance of 25 paths over 4 waves.
 //   * Doppler (float64 phases per tap) is its own instantiation: its registers would halve the others' occupancy.
-// Packed-fp32 forms the compiler does not select (it keeps a swizzled copy of every twiddle - 56 registers instead of 28 -
-// negates with v_xor and moves halves around for the multiplications by -j: 3 instructions per complex product, 37 per
-// radix-8 butterfly).  op_sel / op_sel_hi pick the 32-bit half that feeds the low / high result, neg_lo / neg_hi negate it.
-// None of these reads a transcendental's result directly (taps and Doppler phasors go through compiler-selected
-// multiplies first), and there are no matrix-core instructions in this file.
-__device__ __forceinline__ float2 cmul_pk(float2 a, float2 b) {              // a * b: 2 instructions, b as it is
-    kv2 r;
-    const kv2 av = {a.x, a.y}, bv = {b.x, b.y};
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"
-        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=&v"(r) : "v"(av), "v"(bv));
-    return make_float2(r[0], r[1]);
-}
-__device__ __forceinline__ float2 cadd_mj(float2 a, float2 b) {              // a + (-j) b = (a.x + b.y, a.y - b.x)
-    kv2 r;
-    const kv2 av = {a.x, a.y}, bv = {b.x, b.y};
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(av), "v"(bv));
-    return make_float2(r[0], r[1]);
-}
-__device__ __forceinline__ float2 csub_mj(float2 a, float2 b) {              // a - (-j) b = (a.x - b.y, a.y + b.x)
-    kv2 r;
-    const kv2 av = {a.x, a.y}, bv = {b.x, b.y};
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(av), "v"(bv));
-    return make_float2(r[0], r[1]);
-}
-__device__ __forceinline__ float2 rot1_pk(float2 b) {                        // sqrt(2) e^{-j pi/4} b = (x + y, y - x)
-    kv2 r;
-    const kv2 bv = {b.x, b.y};
-    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(bv));
-    return make_float2(r[0], r[1]);
-}
-__device__ __forceinline__ float2 rot3_pk(float2 b) {                        // sqrt(2) e^{-j 3pi/4} b = (y - x, -x - y)
-    kv2 r;
-    const kv2 bv = {b.x, b.y};
-    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[1,0] neg_hi:[1,1]" : "=v"(r) : "v"(bv));
-    return make_float2(r[0], r[1]);
-}
-__device__ __forceinline__ float2 cscale(float2 a, float s) { const kv2 r = kv2{a.x, a.y} * s; return make_float2(r[0], r[1]); }
-// radix-8 butterfly, 28 packed instructions (dft_small<8> with the -j factors folded into the additions)
-__device__ __forceinline__ void dft8_pk(float2 (&v)[8]) {
-    constexpr float H = 0.70710678118654752f;
-    float2 a[4], b[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { a[k] = caddf(v[k], v[k + 4]); b[k] = csubf(v[k], v[k + 4]); }
-    const float2 b1 = cscale(rot1_pk(b[1]), H), b3 = cscale(rot3_pk(b[3]), H);
-    const float2 t0 = caddf(a[0], a[2]), t1 = csubf(a[0], a[2]), t2 = caddf(a[1], a[3]), d = csubf(a[1], a[3]);
-    v[0] = caddf(t0, t2); v[2] = cadd_mj(t1, d); v[4] = csubf(t0, t2); v[6] = csub_mj(t1, d);
-    const float2 u0 = cadd_mj(b[0], b[2]), u1 = csub_mj(b[0], b[2]), u2 = caddf(b1, b3), e = csubf(b1, b3);
-    v[1] = caddf(u0, u2); v[3] = cadd_mj(u1, e); v[5] = csubf(u0, u2); v[7] = csub_mj(u1, e);
-}
-
 template <bool PACK>
 __device__ __forceinline__ void store_gain(float2* grow, uint2* prow, int k, float2 g, float m1) {
     if constexpr (PACK) {
@@ -544,6 +545,228 @@ __global__ __launch_bounds__(256) void k3_lpf_fft512(WsView ws, LpfArgs a, int64
     }
 }
 
+// ---- the same scheme for N = 64, 128, 256 and 1024 ------------------------------------------------------------------
+// LP = min(64, N / 8) lanes transform one path (64 / LP paths per wave for N < 512), a lane holds the E = N / LP points
+// j + LP m (j = lane % LP) - taps in, bins out.  Every pass reads and writes that pattern: passes 1 and 2 are radix 8
+// (E / 8 butterflies per lane, butterfly t on points t + r E/8; pass 2's twiddles exp(-j 2pi (j & 7) r / 64)), pass 3
+// has radix N / 64 (2, 4: 64 / LP butterflies per lane; 16 for N = 1024: one) with twiddles exp(-j 2pi (j + LP t) r / N).
+// N = 64 ends after pass 2.  N = 512 keeps its own kernel above (one butterfly per lane and pass, nothing indexed).
+__device__ __forceinline__ void dft16_pk(float2 (&x)[16]) {                  // x[r] -> X[r], 4 x 4
+    constexpr float H = 0.70710678118654752f, C1 = 0.92387953251128674f, S1 = 0.38268343236508977f;
+    float2 u[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {                                            // DFT-4 over c of x[a + 4 c] -> u[a][q]
+        float2 t[4] = {x[a], x[a + 4], x[a + 8], x[a + 12]};
+        const float2 t0 = caddf(t[0], t[2]), t1 = csubf(t[0], t[2]), t2 = caddf(t[1], t[3]), d = csubf(t[1], t[3]);
+        u[a][0] = caddf(t0, t2); u[a][1] = cadd_mj(t1, d); u[a][2] = csubf(t0, t2); u[a][3] = csub_mj(t1, d);
+    }
+    // twiddles W16^(a q): W16 = (C1, -S1), W16^2 = H (1, -1), W16^3 = (S1, -C1), W16^4 = -j, W16^6 = H (-1, -1), W16^9 = -W16
+    u[1][1] = cmul_pk(u[1][1], make_float2(C1, -S1));
+    u[1][2] = cscale(rot1_pk(u[1][2]), H);
+    u[1][3] = cmul_pk(u[1][3], make_float2(S1, -C1));
+    u[2][1] = cscale(rot1_pk(u[2][1]), H);
+    u[2][2] = mul_mi(u[2][2]);
+    u[2][3] = cscale(rot3_pk(u[2][3]), H);
+    u[3][1] = cmul_pk(u[3][1], make_float2(S1, -C1));
+    u[3][2] = cscale(rot3_pk(u[3][2]), H);
+    u[3][3] = cmul_pk(u[3][3], make_float2(-C1, S1));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                                            // DFT-4 over a of u[a][q] -> X[q + 4 p]
+        const float2 t0 = caddf(u[0][q], u[2][q]), t1 = csubf(u[0][q], u[2][q]), t2 = caddf(u[1][q], u[3][q]), d = csubf(u[1][q], u[3][q]);
+        x[q] = caddf(t0, t2); x[q + 4] = cadd_mj(t1, d); x[q + 8] = csubf(t0, t2); x[q + 12] = csub_mj(t1, d);
+    }
+}
+
+template <int LOG2N, bool IDENT, bool PACK, bool DOPPLER>
+__global__ __launch_bounds__(256) void k3_lpf_fft_pow2(WsView ws, LpfArgs a, int64_t user_count) {
+    constexpr int N = 1 << LOG2N;
+    constexpr int LP = N >= 512 ? 64 : N / 8;              // lanes per path
+    constexpr int PW = 64 / LP;                            // paths per wave
+    constexpr int E = N / LP;                              // points per lane (8; 16 for N = 1024)
+    constexpr int S1 = E / 8;                              // radix-8 butterflies per lane in passes 1 and 2
+    constexpr int R3 = N / 64;                             // radix of pass 3 (1 = no pass 3)
+    constexpr int S3 = R3 > 1 ? E / R3 : 1;                // its butterflies per lane
+    static_assert(LOG2N >= 6 && LOG2N <= 10 && LOG2N != 9, "N = 64, 128, 256, 1024");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane / LP, j = lane % LP;
+    float2* X = reinterpret_cast<float2*>(smem) + (size_t)(wave * PW + g) * lpf_buf_elems(N);
+    float2 tw2[8];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) {
+        float s, c;
+        sincos_rev(frac_rev(-(double)((j & 7) * r) / 64.0), s, c);
+        tw2[r] = make_float2(c, s);
+    }
+    // pass 3: exp(-j 2pi (j + LP t) r / N).  N = 1024 (one butterfly of 16): the powers 1..3 and 4, 8, 12 of w = W^j,
+    // w^(4a+b) = w^(4a) w^b.  Otherwise S3 x (R3 - 1) values.
+    constexpr int NT3 = R3 == 16 ? 6 : (R3 > 1 ? S3 * (R3 - 1) : 1);
+    float2 tw3[NT3];
+    if constexpr (R3 == 16) {
+        const int pw[6] = {1, 2, 3, 4, 8, 12};
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float s, c;
+            sincos_rev(frac_rev(-(double)(j * pw[i]) / (double)N), s, c);
+            tw3[i] = make_float2(c, s);
+        }
+    } else if constexpr (R3 > 1) {
+#pragma unroll
+        for (int t = 0; t < S3; ++t)
+#pragma unroll
+            for (int r = 1; r < R3; ++r) {
+                float s, c;
+                sincos_rev(frac_rev(-(double)((j + LP * t) * r) / (double)N), s, c);
+                tw3[t * (R3 - 1) + r - 1] = make_float2(c, s);
+            }
+    }
+    const float jf = (float)j;
+    const unsigned sgn = (j & 1) ? 0u : 0x80000000u;       // LP is even: (-1)^d = (-1)^j for every point of the lane
+    int binreg[E];
+    if constexpr (!IDENT) {
+#pragma unroll
+        for (int m = 0; m < E; ++m) { const int k = j + LP * m; binreg[m] = k < a.K ? fpad(a.sc[k] & (N - 1)) : 0; }
+    }
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t ul = (int64_t)blockIdx.x * 4 + wave; ul < user_count; ul += nwaves) {
+        const int64_t u = a.user_begin + ul;
+        const int n_keep = ws.n_keep[u];
+        const size_t rb = (size_t)u * ws.P;
+        const bool lok = lane < n_keep;
+        const float dn_l = lok ? ws.dn[rb + lane] : 0.f;
+        float cr_l = lok ? ws.c_re[rb + lane] : 0.f, ci_l = lok ? ws.c_im[rb + lane] : 0.f;
+        const float dv_l = (lok && DOPPLER) ? ws.dop_v[rb + lane] : 0.f, da_l = (lok && DOPPLER) ? ws.dop_a[rb + lane] : 0.f;
+        const float s0_l = (float)(sinpi((double)dn_l) * (1.0 / LPF_PI));
+        if constexpr (PACK) {
+            float m = lane < (n_keep < 32 ? n_keep : 32) ? fmaxf(fabsf(cr_l), fabsf(ci_l)) : 0.f;
+            for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+            int e;
+            (void)frexpf(m, &e);
+            const float gsl = ldexpf(1.0f, 8 - e);
+            cr_l *= gsl; ci_l *= gsl;
+        }
+        for (int l0 = 0; l0 < n_keep; l0 += PW) {
+            const int l = l0 + g;                          // this lane group's path; groups past n_keep compute zeros and store nothing
+            const bool act = l < n_keep;
+            const int ls = act ? l : 0;
+            // every shuffle outside any `act ? :` - inside, only the active groups' lanes execute it and a source lane in an
+            // idle group (the last path of a user: slot l0 + g >= the active lanes) returns 0
+            const float dnf = __shfl(dn_l, ls), crs = __shfl(cr_l, ls), cis = __shfl(ci_l, ls);
+            const float cr = act ? crs : 0.f, ci = act ? cis : 0.f;
+            const float S = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, __shfl(s0_l, ls)) ^ sgn);
+            const kv2 cs = kv2{cr * S, ci * S};
+            const float x0 = jf - dnf;
+            float2 v[E];
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                const kv2 t = cs * __builtin_amdgcn_rcpf(x0 + (float)(LP * m));
+                v[m] = make_float2(t[0], t[1]);
+            }
+            const bool whole = dnf == rintf(dnf) && dnf >= 0.f && dnf < (float)N;    // np.sinc(0) = 1: s0 = 0, the other taps 0
+            if (__builtin_amdgcn_ballot_w64(whole) != 0) {
+                const int d0 = (int)dnf;
+#pragma unroll
+                for (int m = 0; m < E; ++m)
+                    if (whole) v[m] = (j + LP * m == d0) ? make_float2(cr, ci) : make_float2(0.f, 0.f);
+            }
+            if constexpr (DOPPLER) {
+                const double dv = (double)__shfl(dv_l, ls), da = (double)__shfl(da_l, ls);
+#pragma unroll
+                for (int m = 0; m < E; ++m) {
+                    const double tau = a.ts * (double)(j + LP * m);
+                    const double rev = -a.fc * (dv * tau / LPF_C0 + da * (tau * tau) / (2.0 * LPF_C0));
+                    float s, c;
+                    sincos_rev(frac_rev(rev), s, c);
+                    v[m] = cmulf(v[m], make_float2(c, s));
+                }
+            }
+            // pass 1 (radix 8, no twiddles): butterfly b = j + LP t on points t + r S1 -> elements 8 b + r
+#pragma unroll
+            for (int t = 0; t < S1; ++t) {
+                float2 w[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) w[r] = v[t + r * S1];
+                dft8_pk(w);
+                float2* dst = X + fpad(8 * (j + LP * t));
+#pragma unroll
+                for (int r = 0; r < 8; ++r) dst[r] = w[r];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            // pass 2 (radix 8, Ns = 8): elements b + r N/8 = j + LP (t + r S1) -> 64 (b >> 3) + (b & 7) + 8 r
+#pragma unroll
+            for (int m = 0; m < E; ++m) v[m] = X[fpad(j + LP * m)];
+#pragma unroll
+            for (int t = 0; t < S1; ++t) {
+                float2 w[8];
+                w[0] = v[t];
+#pragma unroll
+                for (int r = 1; r < 8; ++r) w[r] = cmul_pk(v[t + r * S1], tw2[r]);
+                dft8_pk(w);
+                const int b = j + LP * t;
+                float2* dst = X + fpad(64 * (b >> 3) + (b & 7));
+#pragma unroll
+                for (int r = 0; r < 8; ++r) dst[8 * r + (r >> 1)] = w[r];
+            }
+            if constexpr (R3 > 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                // pass 3 (radix R3, Ns = 64): elements b + 64 r = j + LP (t + r S3) -> bins b + 64 r, the same pattern
+#pragma unroll
+                for (int m = 0; m < E; ++m) v[m] = X[fpad(j + LP * m)];
+                if constexpr (R3 == 16) {
+                    float2 w[16];
+                    w[0] = v[0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) {
+                        const float2 lo = tw3[(r & 3) - 1 < 0 ? 0 : (r & 3) - 1], hi = tw3[2 + (r >> 2)];
+                        float2 tw = (r & 3) == 0 ? hi : ((r >> 2) == 0 ? lo : cmul_pk(hi, lo));
+                        w[r] = cmul_pk(v[r], tw);
+                    }
+                    dft16_pk(w);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = w[r];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < S3; ++t) {
+                        float2 w[R3];
+                        w[0] = v[t];
+#pragma unroll
+                        for (int r = 1; r < R3; ++r) w[r] = cmul_pk(v[t + r * S3], tw3[t * (R3 - 1) + r - 1]);
+                        dft_small<R3>(w);
+#pragma unroll
+                        for (int r = 0; r < R3; ++r) v[t + r * S3] = w[r];
+                    }
+                }
+            } else {
+                // N = 64: pass 2 already wrote bins j + 8 r in order; fetch them back into the lane pattern
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int m = 0; m < E; ++m) v[m] = X[fpad(j + LP * m)];
+            }
+            float2* grow = a.gtab + ((size_t)ul * ws.P + ls) * a.K;
+            uint2* prow = reinterpret_cast<uint2*>(grow);
+            if constexpr (!IDENT) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");           // every lane has read its inputs of the last pass
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int m = 0; m < E; ++m) X[fpad(j + LP * m)] = v[m];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int m = 0; m < E; ++m) v[m] = X[binreg[m]];
+            }
+#pragma unroll
+            for (int m = 0; m < E; ++m)
+                if (act && j + LP * m < a.K) store_gain<PACK>(grow, prow, j + LP * m, v[m], ws.neg_one);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");               // the buffer is free for the next path
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 int launch_channels_fd_lpf_contract(const dmx_params& prm, const WsView& ws, int64_t user_begin, int64_t user_count,
                                     const float2* gtab, float2* out, hipStream_t stream, bool packed);
 bool lpf_table_packed(const dmx_params& prm, const WsView& ws);
@@ -605,6 +828,31 @@ static int launch_channels_fd_lpf_once(const dmx_params& prm, const WsView& ws, 
             void* kargs[] = {(void*)&ws, (void*)&a, (void*)&user_count};
             hipError_t le = hipLaunchKernel(kfn, dim3((unsigned)grid), dim3(256), kargs, smem, stream);
             if (le != hipSuccess) { set_error("k3_lpf_fft512 launch failed: %s", hipGetErrorString(le)); return DMX_ERR_LAUNCH; }
+        } else if ((a.N == 64 || a.N == 128 || a.N == 256 || a.N == 1024) && a.K <= a.N && ws.P <= 64 && !old &&
+                   tuning_int("DMX_LPF_GENERIC_FFT", 0) != 1) {
+            // the other default sizes, same scheme (k3_lpf_fft_pow2)
+            a.pack = packed = lpf_table_packed(prm, ws) && tuning_int("DMX_LPF_FLOAT_TABLE", 0) != 1;
+            const bool ident = prm.sc_stride == 1 && (prm.sc_first & (a.N - 1)) == 0;          // host promise: sc[k] = k (mod N)
+            const int v = (ident ? 4 : 0) + (packed ? 2 : 0) + (a.doppler ? 1 : 0);
+#define DMX_FFT_POW2_ROW(L2) {(const void*)k3_lpf_fft_pow2<L2, false, false, false>, (const void*)k3_lpf_fft_pow2<L2, false, false, true>, \
+                              (const void*)k3_lpf_fft_pow2<L2, false, true, false>,  (const void*)k3_lpf_fft_pow2<L2, false, true, true>,  \
+                              (const void*)k3_lpf_fft_pow2<L2, true, false, false>,  (const void*)k3_lpf_fft_pow2<L2, true, false, true>,  \
+                              (const void*)k3_lpf_fft_pow2<L2, true, true, false>,   (const void*)k3_lpf_fft_pow2<L2, true, true, true>}
+            static const void* const kfns[4][8] = {DMX_FFT_POW2_ROW(6), DMX_FFT_POW2_ROW(7), DMX_FFT_POW2_ROW(8), DMX_FFT_POW2_ROW(10)};
+#undef DMX_FFT_POW2_ROW
+            const void* kfn = kfns[a.N == 64 ? 0 : (a.N == 128 ? 1 : (a.N == 256 ? 2 : 3))][v];
+            const int pw = a.N >= 512 ? 1 : 512 / a.N;                                          // paths per wave
+            const size_t smem = (size_t)4 * pw * lpf_buf_elems(a.N) * 8;
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, smem) != hipSuccess || per_cu < 1) {
+                (void)hipGetLastError();
+                per_cu = 1;
+            }
+            int64_t grid = (int64_t)device_cu_count() * per_cu;
+            if (grid > (user_count + 3) / 4) grid = (user_count + 3) / 4;
+            void* kargs[] = {(void*)&ws, (void*)&a, (void*)&user_count};
+            hipError_t le = hipLaunchKernel(kfn, dim3((unsigned)grid), dim3(256), kargs, smem, stream);
+            if (le != hipSuccess) { set_error("k3_lpf_fft_pow2 launch failed: %s", hipGetErrorString(le)); return DMX_ERR_LAUNCH; }
         } else if (pow2 && a.N >= 64 && a.N <= 2048 && !old) {
             // tuning build only: DMX_LPF_FLOAT_TABLE=1 keeps the float table
             a.pack = packed = lpf_table_packed(prm, ws) && tuning_int("DMX_LPF_FLOAT_TABLE", 0) != 1;

@@ -648,6 +648,46 @@ def test_rx_filter_fft512_variants(selection, arrays):
         assert_channel_close(H, ref["channel"], what=f"lpf512 {selection} {arrays} doppler={dop}")
 
 
+@pytest.mark.parametrize("arrays", ["mfma", "valu"])
+@pytest.mark.parametrize("selection", ["all", "first_half", "random", "offset"])
+@pytest.mark.parametrize("N", [64, 128, 256, 1024])
+def test_rx_filter_fft_pow2_variants(N, selection, arrays):
+    """k3_lpf_fft_pow2: the register FFT of the other default OFDM sizes - 8, 4 and 2 paths per wave (N = 64, 128, 256:
+    the last lane group runs past a user's path count) and 16 points per lane with a radix-16 last pass (N = 1024);
+    selections stored from registers or through the buffer, packed or float table, Doppler on and off, users with 0, 1, 2
+    and all paths, whole-sample delays."""
+    import deepmimo_amd as dm
+    from oracle import oracle_np as onp
+    n_ue = 9 if N == 1024 else 14
+    rays = onp.synth_rays(n_ue, 25, seed=N + len(selection) + len(arrays), max_delay=N / 10e6 * 1.1, with_doppler=True)
+    rays["delay"][3, :6] = (np.arange(6) * (N // 7) / 10e6).astype(rays["delay"].dtype)     # whole samples, 0 included
+    rays["delay"][4, 0] = (N - 1) / 10e6
+    for k in rays:                                                   # user 5: one path, user 6: none, user 7: two
+        if rays[k].ndim == 2 and rays[k].shape[1] == 25:
+            rays[k][5, 1:] = np.nan
+            rays[k][6, :] = np.nan
+            rays[k][7, 2:] = np.nan
+    rays["power"][8, ~np.isnan(rays["power"][8])] = -80.0            # equal powers: a lost path (the last one sits alone in its
+    #                                                                  lane-group iteration) is an error of 1 / n_paths, not of its luck
+    sel = {"all": np.arange(N), "first_half": np.arange(N // 2), "offset": np.arange(N, 2 * N),
+           "random": np.sort(np.random.default_rng(N).choice(N, max(5, N // 5), replace=False))}[selection]
+    bs, ue = ([8, 4], [2, 2]) if arrays == "mfma" else ([2, 1], [1, 1])
+    case = dict(bs_shape=bs, ue_shape=ue, bs_spacing=0.5, ue_spacing=0.5, bs_rot=[0, 10, 45],
+                bs_pattern="isotropic", ue_pattern="isotropic", num_paths=25, freq_domain=1, subcarriers=N,
+                selected=list(sel), bandwidth=10e6, rx_filter=1, bs_fov=None, ue_fov=None)
+    ue_rot = np.array([0, 0, 0])
+    op = oracle_params(case, ue_rot)
+    for dop in (0, 1):
+        op["enable_doppler"] = dop
+        ref = onp.compute_channels(rays, op, doppler=dict(vel=rays["doppler_vel"], acc=rays["doppler_acc"], carrier_freq=28e9))
+        ds = dm.Dataset(dict(rays))
+        ds["rt_params"] = {"frequency": 28e9}
+        p = _dm_params(case, ue_rot)
+        p.enable_doppler = dop
+        H = ds.compute_channels(p)
+        assert_channel_close(H, ref["channel"], what=f"lpf N={N} {selection} {arrays} doppler={dop}")
+
+
 def test_sionna_export_of_time_domain_channels():
     """(a, tau) samples in Sionna's layout (reference: integrations/sionna_adapter.py:174-200) from TD channels."""
     import deepmimo_amd as dm

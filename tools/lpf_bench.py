@@ -23,9 +23,12 @@ def main():
     ap.add_argument("--workload", default="c3_headline")
     ap.add_argument("--quick", action="store_true", help="skip the plain path and the round-1 FFT")
     ap.add_argument("--plain-only", action="store_true", help="the plain path alone")
+    ap.add_argument("--n", type=int, default=0, help="OFDM size N = K instead of the workload's (512: k3_lpf_fft512; others: the generic k3_lpf_fft_wave)")
     args = ap.parse_args()
     w = dict(bench.WORKLOADS[args.workload])
     w["n_ue"] = args.users
+    if args.n:
+        w["N"] = args.n
     dev = torch.device("cuda", 0)
     eng = ChannelEngine(0)
     rays = eng.upload_rays(bench.synth_device_rays(w["n_ue"], w["L"], 1234, dev))
