@@ -433,9 +433,7 @@ __global__ __launch_bounds__(256) void k3_lpf_fft512(WsView ws, LpfArgs a, int64
     // writes 64 (lane >> 3) + (lane & 7) + 8 r (Stockham autosort, see fft_pass)
     float2* w1 = X + fpad(8 * lane);                       // + r: same pad for all eight
     float2* rd = X + fpad(lane);                           // + 68 r
-    float2* w2 = X + fpad(64 * (lane >> 3) + (lane & 7));  // + 8 r: 64 g + k + 8 r < 64 g + 64, pad = 4 g + (k + 8 r) / 16
-    const int w2hi = (lane & 7);                           // (k + 8 r) >> 4 = r >> 1 for k < 8
-    (void)w2hi;
+    float2* w2 = X + fpad(64 * (lane >> 3) + (lane & 7));  // + 8 r + (r >> 1): 64 g + k + 8 r has pad 4 g + (k + 8 r) / 16, k < 8
     const float lanef = (float)lane;
     const unsigned sgn = (lane & 1) ? 0u : 0x80000000u;    // S = (-1)^d * (-1) * s0: odd d -> +s0, even d -> -s0
     int binreg[8];
