@@ -362,10 +362,10 @@ __device__ __forceinline__ void stage_item(const WsView& ws, const MfmaArgs& a, 
 // vmcnt(N)` with N = the stores issued since (<= 63) retires the DMA without draining the stores.
 //   * The slots are a static __shared__ array of their own: the compiler then knows that the A' fragment reads (dynamic
 //     LDS) do not alias the DMA's destination and puts no vmcnt wait in front of them.
-//   * The slot itself is read by inline asm (8 x ds_read2_b64 + s_waitcnt lgkmcnt(0) in ONE statement): a visible read
+//   * The slot itself is read by inline asm (two statements of 4 x ds_read2_b64 + s_waitcnt lgkmcnt(0)): a visible read
 //     of the DMA's destination would get the compiler's conservative vmcnt wait - the drain this form exists to avoid.
-//     The statement's results pass through ordinary vector instructions (select, rotate) before any MFMA reads them, and
-//     it stands behind the previous strip's 16 stores: nothing of it is near a matrix-core instruction.
+//     Their results pass through ordinary vector instructions (select, rotate) before any MFMA reads them, and they
+//     stand behind the previous strip's last 16 stores: nothing of them is near a matrix-core instruction.
 //   * Only for K a multiple of 16 (every strip full, every piece inside its row, 16-byte aligned): other K take GSRC = 2.
 // What it buys, priced with every user reading user 0's rows (tuning build, DMX_LPF_ALIAS_TABLE=1: the table out of
 // L2; headline shape x 100k users, contraction alone = total - 1.86 ms of FFT): register loads 19.4 ms with the table in
