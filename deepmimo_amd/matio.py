@@ -51,7 +51,28 @@ def _staging(nbytes: int) -> torch.Tensor:
     return buf
 
 
+STAGING_CAP_BYTES = 1 << 30      # page-locked staging per pipeline run; larger scenarios go through in groups of files
+
+
 def load_matrices_to_device(items, device, rx_idxs=None, max_paths: Optional[int] = None) -> dict:
+    """[(path, key), ...] -> {key: tensor}: `_load_group` over groups of files whose payloads fit the staging cap together
+    (a 10-million-receiver scenario has 1 GB per matrix: eight of them are not page-locked at once)."""
+    import os
+    items = list(items)
+    out, group, size = {}, [], 0
+    for it in items:
+        n = os.path.getsize(it[0])
+        if group and size + n > STAGING_CAP_BYTES:
+            out.update(_load_group(group, device, rx_idxs, max_paths))
+            group, size = [], 0
+        group.append(it)
+        size += n
+    if group:
+        out.update(_load_group(group, device, rx_idxs, max_paths))
+    return out
+
+
+def _load_group(items, device, rx_idxs=None, max_paths: Optional[int] = None) -> dict:
     """[(path, key), ...] 2-D ray matrix files -> {key: float32 [n_sel, min(max_paths, cols)] tensor on `device`}.
 
     All fields of a TX/RX pair go through ONE native pipeline, `dmx_mats_to_device` (core.py:241-254 loads them one

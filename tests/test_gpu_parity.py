@@ -453,6 +453,15 @@ def test_device_loader_matches_scipy(tmp_path):
         assert isinstance(devd[k], torch.Tensor) and devd[k].is_cuda and devd[k].dtype == torch.float32
         np.testing.assert_array_equal(devd[k].cpu().numpy(), host[k].astype(np.float32))
     np.testing.assert_array_equal(devd.rx_pos, host.rx_pos)
+    from deepmimo_amd import matio
+    cap = matio.STAGING_CAP_BYTES
+    try:
+        matio.STAGING_CAP_BYTES = 1                                             # every file a pipeline run of its own
+        dev1 = dm.load(str(folder), max_paths=10, rx_sets={1: sel}, device="cuda")
+    finally:
+        matio.STAGING_CAP_BYTES = cap
+    for k in dm.consts.RAY_FIELDS:
+        assert torch.equal(dev1[k].view(torch.int32), devd[k].view(torch.int32))           # bits: NaN padding included
     p = dm.ChannelGenParameters()
     p.bs_antenna.shape = np.array([8, 4])
     Hd, Hh = devd.compute_channels(p), host.compute_channels(p)
