@@ -51,7 +51,8 @@ struct MfmaArgs {
     const float2* gtab;      // [user_count, P, K] or nullptr
     const uint2* gpack;      // the same table in packed f16 hi/lo form (load_b_step_packed) or nullptr
     int adaptive;            // 1 = a weak last K-step may take one product term (stage_item)
-    int alias_table;         // tuning build only (DMX_LPF_ALIAS_TABLE=1): every user reads user 0's gains - the table out of L2, to price its HBM traffic
+    int alias_table;         // tuning build only (DMX_LPF_ALIAS_TABLE=1): every user reads user 0's gains - the table out of L2, to price its HBM
+                             // traffic (a probe for default-policy loads: with the nt DMA loads that ship, all workgroups re-fetch the same evict-first lines)
 };
 
 // One 32-row tile of one strip: 2*NS ds_read_b128 of A' issued together, 3*NS MFMAs, 16 stores.  NS = K-steps that
