@@ -51,6 +51,24 @@ def _staging(nbytes: int) -> torch.Tensor:
     return buf
 
 
+_MI_DTYPES = {1: np.int8, 2: np.uint8, 3: np.int16, 4: np.uint16, 5: np.int32, 6: np.uint32, 7: np.float32, 9: np.float64,
+              12: np.int64, 13: np.uint64}                                    # miTYPE of the stored payload
+_MX_DTYPES = {6: np.float64, 7: np.float32, 8: np.int8, 9: np.uint8, 10: np.int16, 11: np.uint16, 12: np.int32, 13: np.uint32,
+              14: np.int64, 15: np.uint64}                                    # mxCLASS of the array = what loadmat returns
+
+
+def read_matrix_host(path: str, key: str) -> np.ndarray:
+    """One numeric array of a MAT-v5 file as `scipy.io.loadmat(path)[key]` returns it (class dtype, MATLAB dims), through
+    the library's parser: `loadmat` spends 0.45 ms per file before it reads a byte, which is 0.9 of the 4.6 ms a
+    device load of a 105-MB scenario takes (the two small position matrices)."""
+    with open(path, "rb") as f:
+        mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+        info, image = find_array(mm, key)
+        dims = [int(info.dims[i]) for i in range(info.ndim)]
+        a = np.frombuffer(image, dtype=_MI_DTYPES[int(info.data_type)], count=int(np.prod(dims)), offset=int(info.data_offset))
+        return np.array(a.reshape(dims[::-1]).T, dtype=_MX_DTYPES[int(info.class_id)], order="F")
+
+
 STAGING_CAP_BYTES = 1 << 30      # page-locked staging per pipeline run; larger scenarios go through in groups of files
 
 
