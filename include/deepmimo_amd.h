@@ -9,7 +9,8 @@
  * borrowed DEVICE pointers + sizes in, caller-allocated DEVICE buffers out, a hipStream_t passed
  * as void*.  The library allocates nothing, keeps no global state except a thread-local error
  * string (in particular it reads no environment variable), launches asynchronously on the given stream and never
- * synchronises.
+ * synchronises.  One entry point does I/O: dmx_mats_to_device (the loader) opens the files it is given and runs reader
+ * threads for the duration of the call; nothing of either outlives it.
  *
  * Layouts: ray fields are float32 row-major [n_ue, ld] (ld >= n_paths), NaN = "no path", exactly
  * the arrays Dataset holds after core.py:209-219.  The channel tensor is complex64 interleaved
