@@ -806,7 +806,7 @@ static int launch_channels_fd_lpf_once(const dmx_params& prm, const WsView& ws, 
         int log2n = 0;
         while ((1 << log2n) < a.N) ++log2n;
         const bool old = tuning_int("DMX_LPF_OLD_FFT", 0) == 1;       // tuning build only: the workgroup-per-user FFT
-        if (a.N == 512 && ws.P <= 64 && !old && tuning_int("DMX_LPF_GENERIC_FFT", 0) != 1) {
+        if (a.N == 512 && a.K <= 512 && ws.P <= 64 && !old && tuning_int("DMX_LPF_GENERIC_FFT", 0) != 1) {      // (longer selections: the generic kernel)
             // wave per user, N fixed (k3_lpf_fft512); tuning build only: DMX_LPF_GENERIC_FFT=1 takes the generic kernel below
             a.pack = packed = lpf_table_packed(prm, ws) && tuning_int("DMX_LPF_FLOAT_TABLE", 0) != 1;
             const bool ident = prm.sc_stride == 1 && (prm.sc_first & 511) == 0 && a.K <= 512;   // host promise: sc[k] = k (mod N)

@@ -618,7 +618,7 @@ def test_rx_filter_fft_and_mfma_path(N, K):
 
 
 @pytest.mark.parametrize("arrays", ["mfma", "valu", "dma256", "dma320"])
-@pytest.mark.parametrize("selection", ["all512", "first200", "random100", "offset512", "even256"])
+@pytest.mark.parametrize("selection", ["all512", "first200", "random100", "offset512", "even256", "wrap600"])
 def test_rx_filter_fft512_variants(selection, arrays):
     """Every instantiation of the N = 512 wave-per-user FFT (k3_lpf_fft512): selected subcarriers 0..K-1 stored from
     registers (K = 512 unguarded, K = 200 guarded, 512..1023 = the same bins through the stride promise) or any selection
@@ -638,7 +638,7 @@ def test_rx_filter_fft512_variants(selection, arrays):
             rays[k][5, 1:] = np.nan
             rays[k][6, :] = np.nan
     sel = {"all512": np.arange(512), "first200": np.arange(200), "offset512": np.arange(512, 1024),
-           "even256": np.arange(0, 512, 2),
+           "even256": np.arange(0, 512, 2), "wrap600": np.arange(600),        # more subcarriers than bins: the generic FFT kernel
            "random100": np.sort(np.random.default_rng(7).choice(N, 100, replace=False))}[selection]
     bs, ue = {"mfma": ([8, 4], [2, 2]), "valu": ([2, 1], [1, 1]), "dma256": ([8, 8], [2, 2]), "dma320": ([10, 8], [2, 2])}[arrays]
     case = dict(bs_shape=bs, ue_shape=ue, bs_spacing=0.5, ue_spacing=0.5, bs_rot=[0, 10, 45],
