@@ -99,11 +99,22 @@ def _random_config(rng):
     return cfg
 
 
-def random_case(seed):
-    """(config, rays, ue_rotation, oracle params, bs_fov, ue_fov) of sweep seed `seed`."""
+def random_case(seed, lpf_n=None):
+    """(config, rays, ue_rotation, oracle params, bs_fov, ue_fov) of sweep seed `seed`.  lpf_n: the same configuration
+    forced to rx_filter = 1 at that OFDM size, with a selection drawn from a generator of its own (the recorded draw
+    order of the sweep stays what it was): all bins, a stride, the first part, a wrapped run or a random subset."""
     from oracle import oracle_np as onp
     rng = np.random.default_rng(9000 + seed)
     c = _random_config(rng)
+    if lpf_n is not None:
+        r2 = np.random.default_rng(77000 + seed)
+        kind = r2.choice(["all", "stride", "first", "wrap", "random"])
+        c["mode"], c["N"] = "lpf", int(lpf_n)
+        c["sel"] = {"all": np.arange(lpf_n), "stride": np.arange(0, lpf_n, int(r2.integers(2, 5))),
+                    "first": np.arange(int(r2.integers(1, lpf_n + 1))), "wrap": np.arange(lpf_n, 2 * lpf_n),
+                    "random": np.sort(r2.choice(lpf_n, size=int(r2.integers(1, min(lpf_n, 200) + 1)), replace=False))}[str(kind)]
+        c["n_ue"] = min(c["n_ue"], 24 if lpf_n >= 512 else 60)
+        c["max_delay"] = float(r2.choice([0.3, 0.9, 1.2])) * lpf_n / c["bandwidth"]
     n = c["n_ue"]
     rays = onp.synth_rays(n, c["L"], seed=seed, max_delay=c["max_delay"])
     if c["holes"]:

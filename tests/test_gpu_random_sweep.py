@@ -10,9 +10,9 @@ from tests._cases import assert_channel_close, random_case
 pytestmark = pytest.mark.gpu
 
 
-def _run_hip(seed):
+def _run_hip(seed, lpf_n=None):
     import deepmimo_amd as dm
-    c, rays, ue_rot, op, bs_fov, ue_fov = random_case(seed)
+    c, rays, ue_rot, op, bs_fov, ue_fov = random_case(seed, lpf_n)
     fd = c["mode"] != "td"
     p = dm.ChannelGenParameters()
     p.bs_antenna.shape, p.ue_antenna.shape = np.array(c["bs"]), np.array(c["ue"])
@@ -48,6 +48,16 @@ def _check(seed, c, ds, H, ref):
 def test_random_configuration(seed):
     from oracle import oracle_np as onp
     c, rays, op, bs_fov, ue_fov, ds, H = _run_hip(seed)
+    _check(seed, c, ds, H, onp.compute_channels(rays, op, bs_fov=bs_fov, ue_fov=ue_fov))
+
+
+@pytest.mark.parametrize("lpf_n", [128, 256, 512, 1024])
+@pytest.mark.parametrize("seed", range(300, 312))
+def test_random_configuration_rx_filter_sizes(seed, lpf_n):
+    """The sweep's configurations (panels, path counts, rotations, FoV, patterns, NaN holes) with rx_filter = 1 at the OFDM
+    sizes of the register FFT kernels (the sweep itself draws N = 16 / 48 / 64 for rx_filter) and every kind of selection."""
+    from oracle import oracle_np as onp
+    c, rays, op, bs_fov, ue_fov, ds, H = _run_hip(seed, lpf_n)
     _check(seed, c, ds, H, onp.compute_channels(rays, op, bs_fov=bs_fov, ue_fov=ue_fov))
 
 
