@@ -205,12 +205,15 @@ __device__ __forceinline__ uint32_t float_order_key(float f) {
 // compute_channels and bench.py run): the arccos / atan2 / FoV / dipole code is compiled out, which takes the kernel
 // from 228 to far fewer registers, i.e. from 2 to 3-4 waves per SIMD on a kernel that waits on its loads and stores.
 // ZROT (with LEAN): both rotations are exactly zero and the same for every user.
+#ifndef K1_WAVES
+#define K1_WAVES 4                                          // waves per workgroup (every wave works alone)
+#endif
 template <int LPU, bool LEAN, bool ZROT = false>
-__global__ __launch_bounds__(256, LEAN ? 4 : 2) void k1_path_prep(PrepArgs a) {
+__global__ __launch_bounds__(64 * K1_WAVES, (LEAN ? 16 : 8) / K1_WAVES) void k1_path_prep(PrepArgs a) {
     constexpr int UPW = 64 / LPU;                           // users per wave
     const int lane = threadIdx.x & (LPU - 1);               // lane inside the user's group
     const int grp = (threadIdx.x & 63) / LPU;               // which group of the wave
-    const int64_t u_raw = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * UPW + grp;
+    const int64_t u_raw = ((int64_t)blockIdx.x * K1_WAVES + (threadIdx.x >> 6)) * UPW + grp;
     const bool u_ok = u_raw < a.rays.n_ue;
     if (__ballot(u_ok) == 0ull) return;                     // whole wave past the end
     const int64_t u = u_ok ? u_raw : a.rays.n_ue - 1;       // idle group shadows the last user, writes nothing
@@ -240,14 +243,24 @@ __global__ __launch_bounds__(256, LEAN ? 4 : 2) void k1_path_prep(PrepArgs a) {
     for (int j0 = 0; j0 < L; j0 += LPU) {
         const int j = j0 + lane;
         const bool in = u_ok && j < L;
-        const float power = in ? r.power[row + j] : nan32;
-        const float phase = in ? r.phase[row + j] : nan32;
-        const float delay = in ? r.delay[row + j] : nan32;
-        const float aoa_az = in ? r.aoa_az[row + j] : nan32;
-        const float aoa_el = in ? r.aoa_el[row + j] : nan32;
-        const float aod_az = in ? r.aod_az[row + j] : nan32;
-        const float aod_el = in ? r.aod_el[row + j] : nan32;
-        const float inter = in ? r.inter[row + j] : nan32;
+        // Eight loads issued TOGETHER, from an index every lane may read (idle lanes: the user's last path), masked
+        // afterwards.  Written as `in ? array[row + j] : nan`, each load sat alone in a branch of its own with an
+        // `s_waitcnt vmcnt(0)` behind it: eight memory round trips in a row were the 8 us a wave lived (SQ_WAVE_CYCLES /
+        // SQ_WAVES, profiles/r3_d8_summary.txt) and 0.20-0.28 ms of stage 1 per 200k users.
+        const size_t jc = row + (size_t)(j < L ? j : L - 1);
+        const float power_r = r.power[jc], phase_r = r.phase[jc], delay_r = r.delay[jc], aoa_az_r = r.aoa_az[jc];
+        const float aoa_el_r = r.aoa_el[jc], aod_az_r = r.aod_az[jc], aod_el_r = r.aod_el[jc], inter_r = r.inter[jc];
+        const bool dop_rays = a.doppler && r.doppler_vel && r.doppler_acc;       // kernel-uniform
+        float dvel_r = 0.f, dacc_r = 0.f;
+        if (dop_rays) { dvel_r = r.doppler_vel[jc]; dacc_r = r.doppler_acc[jc]; }    // in the same batch
+        const float power = in ? power_r : nan32;
+        const float phase = in ? phase_r : nan32;
+        const float delay = in ? delay_r : nan32;
+        const float aoa_az = in ? aoa_az_r : nan32;
+        const float aoa_el = in ? aoa_el_r : nan32;
+        const float aod_az = in ? aod_az_r : nan32;
+        const float aod_el = in ? aod_el_r : nan32;
+        const float inter = in ? inter_r : nan32;
 
         double zc_t, re_t, im_t, zc_r, re_r, im_r, sphi_t = 0.0, sphi_r = 0.0;
         if constexpr (ZROT) {
@@ -331,9 +344,9 @@ __global__ __launch_bounds__(256, LEAN ? 4 : 2) void k1_path_prep(PrepArgs a) {
                 const double amp = sqrt(pwc / (double)a.n_sc);
                 c_re = (float)(amp * (double)e_re); c_im = (float)(amp * (double)e_im);
             }
-            if (a.doppler && !a.rx_filter && r.doppler_vel && r.doppler_acc) {   // construct_deepmimo.py:267-280
-                const double v = in ? (double)r.doppler_vel[row + j] : 0.0;
-                const double ac = in ? (double)r.doppler_acc[row + j] : 0.0;
+            if (dop_rays && !a.rx_filter) {                                      // construct_deepmimo.py:267-280
+                const double v = in ? (double)dvel_r : 0.0;
+                const double ac = in ? (double)dacc_r : 0.0;
                 const double tau = (double)delay;
                 const double arg = -TWO_PI * a.fc * (v * tau / LIGHTSPEED + ac * (tau * tau) / (2.0 * LIGHTSPEED));
                 double sd, cd;
@@ -381,9 +394,8 @@ __global__ __launch_bounds__(256, LEAN ? 4 : 2) void k1_path_prep(PrepArgs a) {
             a.ws.c_re[wrow + slot] = c_re; a.ws.c_im[wrow + slot] = c_im; a.ws.dn[wrow + slot] = dn;
             a.ws.tx_y[wrow + slot] = ty; a.ws.tx_z[wrow + slot] = tz;
             a.ws.rx_y[wrow + slot] = ry; a.ws.rx_z[wrow + slot] = rz;
-            const bool dop = a.doppler && r.doppler_vel && r.doppler_acc;
-            a.ws.dop_v[wrow + slot] = dop ? r.doppler_vel[row + j] : 0.0f;
-            a.ws.dop_a[wrow + slot] = dop ? r.doppler_acc[row + j] : 0.0f;
+            a.ws.dop_v[wrow + slot] = dvel_r;                                    // 0 without Doppler; `keep` lanes are `in` lanes
+            a.ws.dop_a[wrow + slot] = dacc_r;
         }
         keep_base += __popcll(kb);
     }
@@ -436,14 +448,14 @@ int launch_path_prep(const dmx_rays& rays, const dmx_params& prm, const WsView& 
     bool zrot = lean && !prm.ue_rotation_per_user;
     for (int i = 0; i < 3; ++i) zrot = zrot && prm.bs_rotation[i] == 0.0 && prm.ue_rotation[i] == 0.0;
     if (rays.n_paths <= 32) {
-        const unsigned grid = (unsigned)((rays.n_ue + 7) / 8);
-        if (zrot) hipLaunchKernelGGL((k1_path_prep<32, true, true>), dim3(grid), dim3(256), 0, stream, a);
-        else if (lean) hipLaunchKernelGGL((k1_path_prep<32, true>), dim3(grid), dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((k1_path_prep<32, false>), dim3(grid), dim3(256), 0, stream, a);
+        const unsigned grid = (unsigned)((rays.n_ue + 2 * K1_WAVES - 1) / (2 * K1_WAVES));
+        if (zrot) hipLaunchKernelGGL((k1_path_prep<32, true, true>), dim3(grid), dim3(64 * K1_WAVES), 0, stream, a);
+        else if (lean) hipLaunchKernelGGL((k1_path_prep<32, true>), dim3(grid), dim3(64 * K1_WAVES), 0, stream, a);
+        else hipLaunchKernelGGL((k1_path_prep<32, false>), dim3(grid), dim3(64 * K1_WAVES), 0, stream, a);
     } else {
-        const unsigned grid = (unsigned)((rays.n_ue + 3) / 4);
-        if (lean) hipLaunchKernelGGL((k1_path_prep<64, true>), dim3(grid), dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((k1_path_prep<64, false>), dim3(grid), dim3(256), 0, stream, a);
+        const unsigned grid = (unsigned)((rays.n_ue + K1_WAVES - 1) / K1_WAVES);
+        if (lean) hipLaunchKernelGGL((k1_path_prep<64, true>), dim3(grid), dim3(64 * K1_WAVES), 0, stream, a);
+        else hipLaunchKernelGGL((k1_path_prep<64, false>), dim3(grid), dim3(64 * K1_WAVES), 0, stream, a);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("k1_path_prep launch failed: %s", hipGetErrorString(e)); return DMX_ERR_LAUNCH; }
