@@ -119,3 +119,24 @@ def test_library_reads_no_environment_variable():
     for f in os.listdir(os.path.join(ROOT, "deepmimo_amd", "csrc")):
         if f.endswith((".hip", ".cpp")):
             assert "getenv" not in open(os.path.join(ROOT, "deepmimo_amd", "csrc", f)).read(), f
+
+
+def test_stage_one_requests_its_ray_loads_together():
+    """k1_path_prep: the eight ray matrices of a path (+ the Doppler pair) are requested back to back, with no
+    `s_waitcnt vmcnt(0)` between them.  Written as eight `in ? array[i] : nan` they compiled to a branch and a full wait per
+    load - eight memory round trips in a row, 0.25 instead of 0.16 ms per 200k users."""
+    ks = isa_lint.kernels_of_library(LIB)
+    k1 = {k: v for k, v in ks.items() if "k1_path_prep" in k}
+    assert len(k1) >= 4
+    for name, insts in k1.items():
+        texts = [i.text for i in insts]
+        loads = [n for n, t in enumerate(texts) if t.startswith("global_load_dword ")]
+        assert len(loads) >= 8, (name, len(loads))
+        # the first run of eight loads of the body: all inside a window of 40 instructions, no full wait in between
+        best = None
+        for a in range(len(loads) - 7):
+            b = loads[a + 7]
+            if b - loads[a] <= 40 and not any(t.startswith("s_waitcnt vmcnt(0)") for t in texts[loads[a]:b]):
+                best = (loads[a], b)
+                break
+        assert best is not None, f"{isa_lint.short_name(name)}: no run of eight ray loads without a full wait between them"
